@@ -1,0 +1,146 @@
+/*
+ * rt_oracle.h -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * A plain-C restatement of the reference's primary/shadow ray-trace path
+ * (Sh-Anand/Raytracer-in-CPP: Flyscene::raytraceScene -> traceRay over the
+ * BoxTree octree with area-light soft shadows).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this; the product path
+ * (raytracer-in-cpp_amd/) never includes, links or calls it.
+ *
+ * Parity pin: the full reference cannot be linked in this image (it needs
+ * GLEW/GLFW, which are absent, and stand-ins are not allowed), so this oracle is
+ * pinned against the reference outputs recorded in SURVEY.md Appendix A
+ * (whole-frame result.ppm md5s, traceRay / screenToWorld / tree known answers)
+ * -- see tests/golden/survey_known_answers.json and tests/test_oracle_golden.py --
+ * and against the reference's GL-free headers (Eigen 3.3.7, mtl.hpp, mtlIO.hpp,
+ * arealight.hpp) compiled in place by oracle/ref_probe.cpp.
+ * Extensions (non-square images, N != 25 samples, max_depth, non-default
+ * cameras, illum 5/6/9 branches) have no reference output: "parity unpinned".
+ *
+ * Every function cites the reference file:line (relative to /root/reference) it follows.
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float x, y, z; } ovec3;
+
+/* Material::Mtl  (dependencies/tucano/tucano/materials/mtl.hpp:16-116) */
+typedef struct {
+    float ka[3], kd[3], ks[3];
+    float shininess;        /* Ns, default 10 */
+    float optical_density;  /* Ni, default 0.0 */
+    float dissolve;         /* d,  default 1 */
+    int   illum;            /* default 0 */
+    char  name[128];
+} omtl;
+
+/* One octree node (src/boxTree.hpp:15-22), kept as a pointer-free pool entry. */
+typedef struct {
+    float bmin[3], bmax[3];
+    int   is_leaf, is_empty;
+    int   child[8];         /* pool indices, -1 = none (children.size() is 0 or 8) */
+    int   nchildren;
+    int   nfaces;
+    int  *faces;
+    int   depth;            /* 0 = root (bookkeeping only) */
+} onode;
+
+typedef struct {
+    /* mesh (Tucano::Mesh subset, mesh.hpp / objimporter.hpp) */
+    int    nverts, nnormals, nfaces, nmtls;
+    float *verts;      /* nverts*4 object space (x,y,z,1) */
+    float *normals;    /* nnormals*3 : file vn list + nverts appended, quirk of objimporter.hpp:50-74 */
+    unsigned *face_vid;/* nfaces*3 */
+    int   *face_mat;   /* nfaces */
+    float *face_normal;/* nfaces*3 (object space, mesh.hpp:461-463) */
+    omtl  *mtls;
+    float centroid[3], radius, norm_scale;
+    float shape[12];   /* 3x4 row-major affine: shape_matrix (model.hpp:169-173) */
+    float model[12];   /* 3x4 row-major affine: model_matrix (identity by default) */
+    float *wverts;     /* nverts*3 world-space ((model*shape)*v).head<3>() */
+    /* octree */
+    onode *nodes; int nnodes, cap_nodes;
+    int tree_capacity, tree_maxdepth;
+} oscene;
+
+typedef struct {
+    float center[3];     /* Camera::getCenter  camera.hpp:115-118 */
+    float inv_view[12];  /* 3x4 row-major  getViewMatrix().inverse() */
+    float fovy, aspect;
+    float viewport[4];
+} ocamera;
+
+enum { OLIGHT_POINT = 0, OLIGHT_AREA = 1 };
+
+typedef struct {
+    int   nlights;
+    float pos[25][3];         /* lights (flyscene.cpp:72); fixed bool[25] in the reference (:699,:835) */
+    float color[3];           /* lightrep colour (1,1,0)  flyscene.cpp:68,824 */
+    int   mode;               /* OLIGHT_POINT: stdin "1 1"; OLIGHT_AREA: stdin "1 0" */
+    int   usteps, vsteps;     /* 5,5 in the reference (flyscene.cpp:971) */
+    float len_x, len_y;       /* 0.3, 0.15 */
+} olights;
+
+typedef struct {
+    int width, height;
+    int max_depth;            /* <0 : unbounded, as the reference (level is never tested) */
+    int nthreads;             /* render threads (reference: hardware_concurrency()-1) */
+} oparams;
+
+typedef struct {
+    uint64_t rays_primary, rays_bounce, rays_centre, rays_sample;
+    uint64_t box_tests;       /* BoundingBox::boxIntersect calls inside traceRay/lightStrikes/BoxTree::intersect */
+    uint64_t leaf_tri_refs;   /* sum of faces.size() over intersected non-empty leaves */
+    uint64_t tri_tests;       /* rayTriangleIntersection calls (unique faces) */
+    uint64_t shaded_hits;     /* phongShade calls */
+    uint64_t precull_tests;   /* root-box tests in raytraceScene's serial loop */
+} ostats;
+
+/* ---- scene ---- */
+oscene *orc_load_obj(const char *obj_path);                 /* objimporter.hpp:83-284 + flyscene.cpp:50-56 */
+void    orc_free_scene(oscene *s);
+void    orc_build_tree(oscene *s, int capacity, int maxdepth); /* boxTree.cpp:11-31,88-147 */
+void    orc_set_model_matrix(oscene *s, const float m[12]);
+
+/* ---- camera ---- */
+void orc_default_camera(ocamera *c, int w, int h);           /* flyscene.cpp:46-47, flycamera.hpp:76-86 */
+void orc_yaw_camera(ocamera *c, int w, int h, float yaw);    /* flycamera.hpp:166-191 (extension: animation) */
+void orc_screen_to_world(const ocamera *c, float i, float j, float out[3]); /* camera.hpp:155-173 */
+void orc_default_lights(olights *l, int area);               /* flyscene.cpp:68,72,971 */
+
+/* ---- per-function entry points (unit parity) ---- */
+int   orc_box_intersect(const float bmin[3], const float bmax[3], const float o[3], const float dest[3]); /* boundingBox.cpp:48-83 */
+float orc_ray_triangle(const oscene *s, const float o[3], const float d[3], int face);                   /* flyscene.cpp:787-819 */
+int   orc_tree_intersect(const oscene *s, const float o[3], const float dest[3], int *out_faces, int cap, ostats *st); /* boxTree.cpp:150-173 */
+int   orc_closest_hit(const oscene *s, const float o[3], const float d[3], float *t_out, ostats *st);    /* flyscene.cpp:655-691 */
+int   orc_light_samples(const olights *l, const float p[3], float *out_xyz /* [n*3] */);                 /* flyscene.cpp:962-972, arealight.hpp:15-25 */
+int   orc_light_strikes(const oscene *s, const float hit[3], const float *pts, int n, unsigned char *vis, ostats *st, int is_sample); /* flyscene.cpp:912-954 */
+void  orc_interp_normal(const oscene *s, const float p[3], int face, float out[3]);                      /* flyscene.cpp:864-888 */
+void  orc_phong(const oscene *s, const olights *l, const float origin[3], const float hit[3], int face,
+                const float *lightpts, int nl, float out[3], ostats *st);                                /* flyscene.cpp:822-859 */
+float orc_fresnel(const float I[3], const float N[3], float ior);                                        /* flyscene.cpp:890-910 */
+void  orc_trace_ray(const oscene *s, const olights *l, const float o[3], const float d[3], int level, int max_depth,
+                    const float *lightpts, int nl, float out[3], ostats *st);                            /* flyscene.cpp:651-771 */
+
+/* ---- frame ---- */
+/* Renders rows [row0,row1) of a W x H frame into out_rgb[(row1-row0)*W*3], row-major (y,x).
+   out_hit (optional) gets the level-0 closest-hit face id (-1 miss/culled). flyscene.cpp:519-648 */
+void orc_render(const oscene *s, const ocamera *c, const olights *l, const oparams *p,
+                int row0, int row1, float *out_rgb, int32_t *out_hit, ostats *st);
+/* Same, but only every `stride`-th pixel in x and y of the full frame (bounded CPU-baseline sample). Returns #pixels. */
+long orc_render_subsample(const oscene *s, const ocamera *c, const olights *l, const oparams *p,
+                          int stride, ostats *st, double *seconds);
+/* ppmIO.hpp:130-151 (row j, column i; min(255,(int)(255*c))) */
+int  orc_write_ppm(const char *path, const float *rgb, int w, int h);
+void orc_quantise(const float *rgb, long n, int32_t *out); /* ppmIO.hpp:145 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
