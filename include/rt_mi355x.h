@@ -1,0 +1,190 @@
+/*
+ * rt_mi355x.h -- C ABI of the MI355X-native primary/shadow ray-trace path.
+ *
+ * Drop-in boundary for the reference's CPU ThreadPool render (Sh-Anand/Raytracer-in-CPP).  The reference
+ * has no FFI layer; the boundary is two C++ members (citations relative to /root/reference):
+ *     void            Flyscene::raytraceScene(int width = 0, int height = 0)           src/flyscene.hpp:84
+ *                                                                                      src/flyscene.cpp:519-648
+ *     Eigen::Vector3f Flyscene::traceRay(Vector3f& origin, Vector3f& direction, int level,
+ *                                        vector<Vector3f>& lights, bool countRay)      src/flyscene.hpp:94
+ *                                                                                      src/flyscene.cpp:651-771
+ * called from src/main.cpp:70 (key 'T') and from the pool lambda src/flyscene.cpp:615-623.
+ * Each entry point below names the reference interface it replaces.  Plain pointers and sizes only; no C++,
+ * Eigen, Tucano or torch types cross this boundary.  All functions return RT_OK (0) or a negative rt_status;
+ * nothing throws and nothing calls exit().  A context belongs to one HIP device; rt_render* is blocking and not
+ * re-entrant per context; distinct contexts may be used from distinct threads.
+ *
+ * The library FAILS LOUDLY (RT_ERR_NO_DEVICE / RT_ERR_HIP) when there is no MI355X-class HIP device: there is
+ * no CPU fallback in the product.
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int rt_status;
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,      /* bad argument (NULL, W/H <= 0, L > 25, N not a square grid, ...) */
+    RT_ERR_NO_DEVICE = -2,    /* no HIP device / wrong device index */
+    RT_ERR_HIP = -3,          /* a HIP runtime call failed (see rt_last_error) */
+    RT_ERR_IO = -4,           /* file could not be opened / written */
+    RT_ERR_UNSUPPORTED = -5,  /* scene exceeds a compiled limit (tree depth, samples) */
+    RT_ERR_NO_SCENE = -6      /* render before rt_upload_scene */
+};
+
+#define RT_MAX_LIGHTS 25      /* the reference's fixed bool visibleLights[25]  (flyscene.cpp:699,835) */
+#define RT_MAX_SAMPLES 1024   /* per light; the reference hard-codes 5x5 = 25  (flyscene.cpp:971) */
+#define RT_MAX_DEPTH 15       /* recursion levels kept per pixel (the reference is unbounded) */
+
+/* ---- flattened scene: the device-friendly restatement of BoxTree / Tucano::Mesh / Material::Mtl ------------- */
+/* replaces: class BoxTree (src/boxTree.hpp:15-62), BoundingBox (src/boundingBox.hpp:21-43),
+ *           Tucano::Face (tucano/mesh.hpp:238-247), Material::Mtl (tucano/materials/mtl.hpp:16-116)             */
+typedef struct rt_node {
+    float    bmin[3], bmax[3];
+    uint32_t first;           /* leaf: first index into face_refs; inner: index of first child node            */
+    uint32_t count_flags;     /* low 31 bits: #faces (leaf) or #children (inner); bit 31 set = leaf            */
+} rt_node;                    /* 32 bytes */
+#define RT_NODE_LEAF 0x80000000u
+
+typedef struct rt_material {
+    float kd[3], ks[3];
+    float shininess, optical_density;
+    int32_t illum;
+} rt_material;                /* 36 bytes */
+
+typedef struct rt_scene {
+    uint32_t n_nodes;      const rt_node  *nodes;        /* node 0 = root; children of a node are contiguous    */
+    uint32_t n_face_refs;  const uint32_t *face_refs;    /* leaf face lists, concatenated                       */
+    uint32_t n_faces;
+    const float    *tri_verts;      /* n_faces*9  world-space A,B,C = ((model*shape)*v).head<3>()               */
+    const float    *face_normal;    /* n_faces*3  Face::normal (object space, used untransformed)               */
+    const uint32_t *tri_vid;        /* n_faces*3  vertex ids (index vert_normal)                                */
+    const int32_t  *mat_id;         /* n_faces                                                                  */
+    uint32_t n_vert_normals; const float *vert_normal;   /* *3, mesh.getNormal(vertex_id)                       */
+    uint32_t n_materials;    const rt_material *materials;
+    float model[12];                /* Mesh::getModelMatrix() 3x4 row-major (identity unless modifyTriangle)    */
+} rt_scene;
+
+/* replaces: Tucano::Flycamera state read by raytraceScene (flyscene.cpp:551,575; camera.hpp:115-118,155-173)    */
+typedef struct rt_camera {
+    float center[3];          /* flycamera.getCenter()                                                          */
+    float inv_view[12];       /* getViewMatrix().inverse(), 3x4 row-major                                       */
+    float fovy;               /* degrees; 60 in the reference (flyscene.cpp:46)                                 */
+    float aspect;             /* width/(float)height                                                            */
+    float viewport[4];        /* (0,0,W,H)                                                                      */
+} rt_camera;
+
+enum { RT_LIGHT_POINT = 0, RT_LIGHT_AREA = 1 };
+/* replaces: Flyscene::lights, lightrep colour, the stdin switches areaLight/pointLight (flyscene.cpp:31-34,68,72)
+ * and the literals of createSpherePoint/createAreaLight (flyscene.cpp:956-972, arealight.hpp:15-25)             */
+typedef struct rt_lights {
+    int32_t n_lights;                       /* 1..RT_MAX_LIGHTS                                                 */
+    float   pos[RT_MAX_LIGHTS][3];
+    float   color[3];                       /* (1,1,0)                                                          */
+    int32_t mode;                           /* RT_LIGHT_POINT (1 sample) | RT_LIGHT_AREA (usteps*vsteps)        */
+    int32_t usteps, vsteps;                 /* 5,5 in the reference; 8,8 / 16,16 for the 64 / 256 sample configs */
+    float   len_x, len_y;                   /* 0.3, 0.15                                                        */
+} rt_lights;
+
+/* replaces: the literals inside traceRay / lightStrikes and raytraceScene's image size + thread partitioning    */
+typedef struct rt_params {
+    int32_t width, height;    /* full frame                                                                     */
+    int32_t max_depth;        /* levels 0..max_depth are traced (a hit at level == max_depth is plain Phong);
+                                 <0 = RT_MAX_DEPTH.  The reference never tests `level` (flyscene.cpp:651-771)   */
+    /* row shard (multi-GPU): this call renders the rows y in [row0,row1) with ((y-row0)/stripe) % nranks == rank,
+       in increasing y.  Single GPU: row0=0,row1=height,stripe=1,rank=0,nranks=1.                               */
+    int32_t row0, row1, stripe, rank, nranks;
+    int32_t collect_stats;    /* 0: ray counters + per-kernel times of this call (when stats != NULL; syncs)
+                                 1: also run the counting (no early-out) traversal variants first and fill the
+                                    algorithmic counters; costs a second frame, never set inside a timed region
+                                 2: deferred timing -- record per-kernel HIP events on the launch stream, do NOT
+                                    synchronise; sums are fetched later with rt_timing_collect (bench loops)   */
+} rt_params;
+
+typedef struct rt_stats {
+    /* ray = one traversal query (root AABB test + tree walk)                                                    */
+    uint64_t rays_primary, rays_bounce, rays_centre, rays_sample;
+    uint64_t pixels, pixels_culled;       /* pixels whose primary ray misses the root box (flyscene.cpp:576-581) */
+    uint64_t shaded_hits;                 /* phongShade calls                                                    */
+    /* algorithmic (reference-semantics) counters, only with collect_stats: boxIntersect calls and leaf face
+       references exactly as BoxTree::intersect/traceRay/lightStrikes would perform them (no early-out)         */
+    uint64_t box_tests, leaf_tri_refs;                 /* whole frame (closest-hit + centre + sample rays)      */
+    uint64_t box_tests_shadow, leaf_tri_refs_shadow;   /* the share of the sample-shadow kernel (k_shadow)      */
+    /* per-kernel device time of the last render, milliseconds (HIP events on the render stream)                 */
+    float ms_trace, ms_shadow, ms_shade, ms_resolve, ms_total;
+    uint32_t launches_trace, launches_shadow, launches_shade;
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+
+/* ---- context --------------------------------------------------------------------------------------------- */
+rt_status   rt_create(rt_ctx **out, int device);                     /* replaces: ThreadPool pool(n) flyscene.cpp:609 */
+void        rt_destroy(rt_ctx *ctx);                                 /* replaces: pool.~ThreadPool() flyscene.cpp:634 */
+const char *rt_last_error(const rt_ctx *ctx);                        /* NULL-safe; static string when ctx == NULL     */
+const char *rt_version(void);
+
+/* replaces: the scene state traceRay reads through `this` (octree, mesh, materials).  Arrays are copied.          */
+rt_status rt_upload_scene(rt_ctx *ctx, const rt_scene *scene);
+
+/* replaces: Flyscene::raytraceScene's pixel loop + pool execution (flyscene.cpp:573-629).
+ * out_rgb: host, [n_local_rows * W * 3] float, row-major (y,x); out_hit (optional): level-0 closest face id or -1 */
+rt_status rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_lights *lights, const rt_params *p,
+                    float *out_rgb, int32_t *out_hit, rt_stats *stats);
+
+/* Same, results stay in device memory (for RCCL gathers / chained launches).  d_out_rgb: device float
+ * [n_local_rows*W*3]; d_out_u8 (optional): device uint8 [n_local_rows*W*3] quantised as ppmIO.hpp:145;
+ * stream: hipStream_t (NULL = the context's own stream).  Asynchronous when stats == NULL.                        */
+rt_status rt_render_device(rt_ctx *ctx, const rt_camera *cam, const rt_lights *lights, const rt_params *p,
+                           float *d_out_rgb, uint8_t *d_out_u8, int32_t *d_out_hit, void *stream, rt_stats *stats);
+
+/* Sums the per-kernel device times (ms_* = SUM over frames, launches_* = total launches) of every frame rendered
+ * with collect_stats == 2 since the last call, plus the ray counters of the last frame.  Synchronises the stream.  */
+rt_status rt_timing_collect(rt_ctx *ctx, rt_stats *out);
+
+/* number of rows rt_render produces for p */
+int32_t rt_local_rows(const rt_params *p);
+
+/* replaces: Flyscene::traceRay called directly (debug ray, flyscene.cpp:286; unit parity).  n rays, origin/dir
+ * [n*3]; every ray sees the scene lights.  out_rgb [n*3]; out_face/out_t optional (level-0 closest hit).          */
+rt_status rt_trace_rays(rt_ctx *ctx, const rt_lights *lights, int32_t max_depth, int32_t n,
+                        const float *origin, const float *dir, float *out_rgb, int32_t *out_face, float *out_t);
+
+/* replaces: Flyscene::lightStrikes (flyscene.cpp:912-954): n segments light[i] -> hit[i]; vis[i] = 1 iff visible   */
+rt_status rt_light_strikes(rt_ctx *ctx, int32_t n, const float *hit, const float *light, uint8_t *vis);
+
+/* ---- host-side scene preparation (GL-free restatement of the Tucano loader + BoxTree builder) --------------- */
+typedef struct rt_host_scene rt_host_scene;
+/* replaces: MeshImporter::loadObjFile + mesh.normalizeModelMatrix() + BoxTree(mesh, capacity)
+ *           (flyscene.cpp:50-56,86-93; objimporter.hpp:83-284; boxTree.cpp:11-31)                                 */
+rt_status rt_host_scene_load(const char *obj_path, int32_t leaf_capacity, int32_t max_depth, rt_host_scene **out);
+void      rt_host_scene_free(rt_host_scene *hs);
+/* borrowed view of the flattened arrays (valid until rt_host_scene_free / rt_host_scene_set_model)               */
+rt_status rt_host_scene_view(const rt_host_scene *hs, rt_scene *out);
+/* replaces: Flyscene::modifyTriangle (flyscene.cpp:998-1015): sets the model matrix; rebuild != 0 also rebuilds
+ * the octree (the reference leaves it stale)                                                                     */
+rt_status rt_host_scene_set_model(rt_host_scene *hs, const float model[12], int32_t rebuild_tree);
+/* tree summary: nodes, non-empty leaves, face refs, largest leaf, depth, "lost" faces                             */
+rt_status rt_host_scene_info(const rt_host_scene *hs, int32_t out[8], float root_box[6]);
+
+/* replaces: Flycamera defaults + setPerspectiveMatrix/setViewport (flyscene.cpp:46-47, flycamera.hpp:76-86)       */
+void rt_default_camera(rt_camera *cam, int32_t width, int32_t height);
+/* fly-camera yaw (rotation_Y_axis) for animation paths (flycamera.hpp:166-191)                                    */
+void rt_yaw_camera(rt_camera *cam, int32_t width, int32_t height, float yaw);
+/* replaces: Camera::screenToWorld (camera.hpp:155-173); host evaluation, used to check the device's              */
+void rt_screen_to_world(const rt_camera *cam, float i, float j, float out[3]);
+/* replaces: lights.push_back((-1,1,1)), lightrep colour, areaLight/pointLight stdin (flyscene.cpp:31-34,68,72)    */
+void rt_default_lights(rt_lights *l, int32_t area);
+
+/* replaces: Tucano::ImageImporter::writePPMImage (ppmIO.hpp:130-151): byte-exact ASCII P3                         */
+rt_status rt_write_ppm(const char *path, const float *rgb, int32_t width, int32_t height);
+rt_status rt_write_ppm_u8(const char *path, const uint8_t *rgb8, int32_t width, int32_t height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */

@@ -236,7 +236,9 @@ oscene *orc_load_obj(const char *obj_path) {
         float radius = 0.0f;
         for (int i = 0; i < nv; i++) {
             float d[3]; sub3(&vert[i * 4], c, d);
-            float nrm = sqrtf(dot3(d, d));
+            /* ( vert[i].head(3) - centroid ).norm(): a dynamic-size block expression -> left-to-right sum
+               (pinned by oracle/ref_probe.cpp, key head3_minus_fixed_norm) */
+            float nrm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
             radius = stdmaxf(radius, nrm);
         }
         s->centroid[0] = c[0]; s->centroid[1] = c[1]; s->centroid[2] = c[2];
@@ -978,4 +980,60 @@ int orc_write_ppm(const char *path, const float *rgb, int w, int h) {
     }
     fclose(f);
     return 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* accessors for the Python test harness (tests/oracle_lib.py)         */
+/* ------------------------------------------------------------------ */
+void orc_scene_counts(const oscene *s, int out[8]) {
+    out[0] = s->nverts; out[1] = s->nnormals; out[2] = s->nfaces; out[3] = s->nmtls; out[4] = s->nnodes;
+    out[5] = s->tree_capacity; out[6] = s->tree_maxdepth; out[7] = 0;
+}
+const float *orc_scene_wverts(const oscene *s) { return s->wverts; }
+const float *orc_scene_normals(const oscene *s) { return s->normals; }
+const float *orc_scene_face_normals(const oscene *s) { return s->face_normal; }
+const unsigned *orc_scene_face_vid(const oscene *s) { return s->face_vid; }
+const int *orc_scene_face_mat(const oscene *s) { return s->face_mat; }
+void orc_scene_mtl(const oscene *s, int i, float out[8], int *illum) {
+    const omtl *m = &s->mtls[i];
+    out[0] = m->kd[0]; out[1] = m->kd[1]; out[2] = m->kd[2]; out[3] = m->ks[0]; out[4] = m->ks[1]; out[5] = m->ks[2];
+    out[6] = m->shininess; out[7] = m->optical_density; *illum = m->illum;
+}
+/* node i: box[6], flags {is_leaf,is_empty,nchildren,nfaces,depth}, children[8]; faces copied into out_faces (cap) */
+int orc_scene_node(const oscene *s, int i, float box[6], int flags[5], int children[8], int *out_faces, int cap) {
+    const onode *n = &s->nodes[i];
+    for (int k = 0; k < 3; k++) { box[k] = n->bmin[k]; box[3 + k] = n->bmax[k]; }
+    flags[0] = n->is_leaf; flags[1] = n->is_empty; flags[2] = n->nchildren; flags[3] = n->nfaces; flags[4] = n->depth;
+    for (int k = 0; k < 8; k++) children[k] = n->child[k];
+    int m = n->nfaces < cap ? n->nfaces : cap;
+    if (out_faces && m > 0) memcpy(out_faces, n->faces, sizeof(int) * (size_t)m);
+    return n->nfaces;
+}
+
+/* ------------------------------------------------------------------ */
+/* The oracle's vector conventions, exposed so tests can pin them bit-for-bit against the reference's real       */
+/* Eigen 3.3.7 / Tucano headers (tests/golden/eigen_probe.json, produced by oracle/ref_probe.cpp).              */
+/* out layout: see tests/test_eigen_probe.py                                                                     */
+/* ------------------------------------------------------------------ */
+void orc_vec_ops(const float a[3], const float b[3], const float c[3], float u, float v, float w, float sum, int steps,
+                 int idx, float scale, float out[64]) {
+    int k = 0;
+    out[k++] = dot3(a, b);
+    out[k++] = dot3(a, a);
+    { float t[3]; cross3(a, b, t); memcpy(&out[k], t, 12); k += 3; }
+    { float t[3] = {a[0], a[1], a[2]}; normalize3_fixed(t); memcpy(&out[k], t, 12); k += 3; }
+    { float t[3]; sub3(a, b, t); normalize3_dyn(t); memcpy(&out[k], t, 12); k += 3; }             /* head3_diff_normalized */
+    { float t[3]; sub3(a, c, t); out[k++] = sqrtf((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]); }     /* head3_minus_fixed_norm */
+    for (int i = 0; i < 3; i++) out[k++] = 0.15f * a[i] + 0.85f * b[i];
+    for (int i = 0; i < 3; i++) out[k++] = 0.10f * a[i] + 0.90f * b[i];
+    for (int i = 0; i < 3; i++) out[k++] = 0.2f * a[i] + 0.8f * b[i];
+    { float two = 2 * dot3(a, b); for (int i = 0; i < 3; i++) out[k++] = a[i] - two * b[i]; }     /* reflect */
+    for (int i = 0; i < 3; i++) out[k++] = (u * a[i] + v * b[i]) + w * c[i];                       /* bary */
+    { float n = 25.0f; float A = sum / n, B = 1.3f / n; for (int i = 0; i < 3; i++) out[k++] = c[i] + (a[i] * A) * B; }
+    for (int i = 0; i < 3; i++) out[k++] = (float)(idx + 0.5) * (a[i] / (float)steps);             /* area_scale */
+    { float vx[3] = {a[0], 0, 0}, vy[3] = {0, a[1], 0}, vz[3] = {0, 0, a[2]};
+      for (int i = 0; i < 3; i++) out[k++] = ((b[i] + vx[i]) + vy[i]) + 2.0f * vz[i]; }            /* octant_max */
+    { /* world vertex: shape = I.scale(s).translate(-c); (I * shape) * (a,1) */
+      for (int i = 0; i < 3; i++) { float t = 0.0f + scale * (-c[i]); out[k++] = scale * a[i] + t; } }
+    out[k++] = 0.f;
 }

@@ -140,6 +140,18 @@ long orc_render_subsample(const oscene *s, const ocamera *c, const olights *l, c
 int  orc_write_ppm(const char *path, const float *rgb, int w, int h);
 void orc_quantise(const float *rgb, long n, int32_t *out); /* ppmIO.hpp:145 */
 
+/* accessors for the Python test harness */
+void orc_scene_counts(const oscene *s, int out[8]);
+const float *orc_scene_wverts(const oscene *s);
+const float *orc_scene_normals(const oscene *s);
+const float *orc_scene_face_normals(const oscene *s);
+const unsigned *orc_scene_face_vid(const oscene *s);
+const int *orc_scene_face_mat(const oscene *s);
+void orc_scene_mtl(const oscene *s, int i, float out[8], int *illum);
+void orc_vec_ops(const float a[3], const float b[3], const float c[3], float u, float v, float w, float sum, int steps,
+                 int idx, float scale, float out[64]);
+int orc_scene_node(const oscene *s, int i, float box[6], int flags[5], int children[8], int *out_faces, int cap);
+
 #ifdef __cplusplus
 }
 #endif

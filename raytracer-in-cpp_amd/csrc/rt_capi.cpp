@@ -1,0 +1,575 @@
+// rt_capi.cpp -- implementation of the C ABI declared in include/rt_mi355x.h: context, scene upload,
+// frame orchestration (a fixed, host-sync-free launch sequence per frame) and the host-scene wrappers.
+// No CPU fallback exists here: without a HIP device every entry point that needs one fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host_scene.hpp"
+#include "rt_device.hpp"
+#include "rt_mi355x.h"
+
+namespace rtamd {
+void launch_trace(bool primary, bool count, int grid, hipStream_t st, const DScene &S, const DCam &cam, const DLights &L, const DFrame &F,
+                  int level, int slot, const RayItem *rays_in, ShadeItem *items, Control *ctl, float4 *rec, int32_t *out_hit, float *out_t);
+void launch_shadow(bool count, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
+                   const ShadeItem *items, Control *ctl, unsigned long long *vis);
+void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level, int slot, int lslots,
+                  const ShadeItem *items, Control *ctl, const unsigned long long *vis, float4 *rec, float *fres, RayItem *rays_out);
+void launch_resolve(int grid, hipStream_t st, const DFrame &F, const float4 *rec, const float *fres, float *out_rgb, uint8_t *out_u8);
+void launch_segments(int grid, hipStream_t st, const DScene &S, int n, const float *hit, const float *light, uint8_t *vis);
+}  // namespace rtamd
+
+using namespace rtamd;
+
+struct rt_host_scene {
+    HostScene hs;
+};
+
+struct rt_ctx {
+    int device = 0;
+    int cus = 256;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // scene
+    bool has_scene = false;
+    DScene S{};
+    void *d_nodes = nullptr, *d_tris = nullptr, *d_tri_verts = nullptr, *d_face_normal = nullptr, *d_tri_vid = nullptr,
+         *d_mat_id = nullptr, *d_vert_normal = nullptr, *d_mats = nullptr;
+    bool reflective = false;     // some material spawns bounce rays (illum 3,4,5,6,9)
+    // frame buffers
+    size_t cap_pix = 0;
+    int cap_levels = 0;
+    size_t cap_vis = 0;
+    RayItem *d_rays[2] = {nullptr, nullptr};
+    ShadeItem *d_items = nullptr;
+    unsigned long long *d_vis = nullptr;
+    float4 *d_rec = nullptr;
+    float *d_fres = nullptr;
+    Control *d_ctl = nullptr;
+    float *d_rgb = nullptr;      // staging for rt_render (host output)
+    int32_t *d_hit = nullptr;
+    float *d_t = nullptr;
+    size_t cap_out = 0;
+    std::vector<hipEvent_t> events;
+    // deferred timing (collect_stats == 2): events are not reused until rt_timing_collect
+    size_t ev_base = 0;                       // first free event index
+    std::vector<std::pair<size_t, int>> pending;   // (first event, levels_run) per frame
+    hipStream_t pending_stream = nullptr;
+    DFrame pending_frame{};
+};
+
+static const char *k_no_ctx = "rt_mi355x: null context";
+
+#define HIPCHK(ctx, call)                                                                                      \
+    do {                                                                                                       \
+        hipError_t e_ = (call);                                                                                \
+        if (e_ != hipSuccess) {                                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                    \
+            return RT_ERR_HIP;                                                                                 \
+        }                                                                                                      \
+    } while (0)
+
+extern "C" const char *rt_version(void) { return "rt_mi355x 0.1 (gfx950)"; }
+
+extern "C" const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->err.c_str() : k_no_ctx; }
+
+extern "C" rt_status rt_create(rt_ctx **out, int device) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        std::fprintf(stderr, "rt_mi355x: no HIP device visible -- this library has no CPU fallback\n");
+        return RT_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) return RT_ERR_NO_DEVICE;
+    rt_ctx *c = new rt_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return RT_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RT_ERR_HIP; }
+    if (hipMalloc(reinterpret_cast<void **>(&c->d_ctl), sizeof(Control)) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return RT_ERR_HIP; }
+    *out = c;
+    return RT_OK;
+}
+
+static void free_scene(rt_ctx *c) {
+    void **p[] = {&c->d_nodes, &c->d_tris, &c->d_tri_verts, &c->d_face_normal, &c->d_tri_vid, &c->d_mat_id, &c->d_vert_normal, &c->d_mats};
+    for (void **q : p) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    c->has_scene = false;
+}
+
+static void free_frame(rt_ctx *c) {
+    if (c->d_rays[0]) (void)hipFree(c->d_rays[0]);
+    if (c->d_rays[1]) (void)hipFree(c->d_rays[1]);
+    if (c->d_items) (void)hipFree(c->d_items);
+    if (c->d_vis) (void)hipFree(c->d_vis);
+    if (c->d_rec) (void)hipFree(c->d_rec);
+    if (c->d_fres) (void)hipFree(c->d_fres);
+    c->d_rays[0] = c->d_rays[1] = nullptr; c->d_items = nullptr; c->d_vis = nullptr; c->d_rec = nullptr; c->d_fres = nullptr;
+    c->cap_pix = 0; c->cap_levels = 0; c->cap_vis = 0;
+}
+
+extern "C" void rt_destroy(rt_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    free_frame(c);
+    if (c->d_rgb) (void)hipFree(c->d_rgb);
+    if (c->d_hit) (void)hipFree(c->d_hit);
+    if (c->d_t) (void)hipFree(c->d_t);
+    if (c->d_ctl) (void)hipFree(c->d_ctl);
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+template <typename T>
+static rt_status upload(rt_ctx *c, void **dst, const T *src, size_t n) {
+    const size_t bytes = (n ? n : 1) * sizeof(T);
+    HIPCHK(c, hipMalloc(dst, bytes));
+    if (n) HIPCHK(c, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
+    if (!c) return RT_ERR_INVALID;
+    if (!sc || !sc->nodes || sc->n_nodes == 0 || !sc->materials || sc->n_materials == 0) { c->err = "rt_upload_scene: empty scene"; return RT_ERR_INVALID; }
+    if (sc->n_faces && (!sc->tri_verts || !sc->face_normal || !sc->tri_vid || !sc->mat_id || !sc->vert_normal)) { c->err = "rt_upload_scene: missing arrays"; return RT_ERR_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    // validate indices and the depth bound of the traversal stack before anything reaches a kernel
+    std::vector<int> depth(sc->n_nodes, 0);
+    int max_depth = 0;
+    for (uint32_t i = 0; i < sc->n_nodes; ++i) {
+        const rt_node &n = sc->nodes[i];
+        const uint32_t cnt = n.count_flags & 0x7fffffffu;
+        if (n.count_flags & RT_NODE_LEAF) {
+            if (static_cast<uint64_t>(n.first) + cnt > sc->n_face_refs) { c->err = "rt_upload_scene: leaf range outside face_refs"; return RT_ERR_INVALID; }
+        } else {
+            if (cnt > 8 || (cnt && (n.first <= i || static_cast<uint64_t>(n.first) + cnt > sc->n_nodes))) { c->err = "rt_upload_scene: bad child range"; return RT_ERR_INVALID; }
+            for (uint32_t k = 0; k < cnt; ++k) depth[n.first + k] = depth[i] + 1;
+        }
+        if (depth[i] > max_depth) max_depth = depth[i];
+    }
+    if (max_depth > 16) { c->err = "rt_upload_scene: octree deeper than 16 levels (traversal stack bound)"; return RT_ERR_UNSUPPORTED; }
+    for (uint32_t i = 0; i < sc->n_face_refs; ++i)
+        if (sc->face_refs[i] >= sc->n_faces) { c->err = "rt_upload_scene: face ref out of range"; return RT_ERR_INVALID; }
+    for (uint32_t f = 0; f < sc->n_faces; ++f) {
+        if (sc->mat_id[f] < 0 || static_cast<uint32_t>(sc->mat_id[f]) >= sc->n_materials) { c->err = "rt_upload_scene: material id out of range"; return RT_ERR_INVALID; }
+        for (int k = 0; k < 3; ++k)
+            if (sc->tri_vid[f * 3 + k] >= sc->n_vert_normals) { c->err = "rt_upload_scene: vertex id outside vert_normal"; return RT_ERR_INVALID; }
+    }
+
+    // leaf-ordered triangle records: the per-triangle constants of rayTriangleIntersection (flyscene.cpp:787-811),
+    // evaluated once with the same float operations the reference performs on every call
+    std::vector<TriRec> recs(sc->n_face_refs);
+    for (uint32_t i = 0; i < sc->n_face_refs; ++i) {
+        const uint32_t f = sc->face_refs[i];
+        const float *v = sc->tri_verts + static_cast<size_t>(f) * 9;
+        const float *n = sc->face_normal + static_cast<size_t>(f) * 3;
+        TriRec &r = recs[i];
+        const V3 A{v[0], v[1], v[2]}, B{v[3], v[4], v[5]}, C{v[6], v[7], v[8]}, N{n[0], n[1], n[2]};
+        const V3 e0 = C - A, e1 = B - A;
+        r.ax = A.x; r.ay = A.y; r.az = A.z;
+        r.e0x = e0.x; r.e0y = e0.y; r.e0z = e0.z;
+        r.e1x = e1.x; r.e1y = e1.y; r.e1z = e1.z;
+        r.nx = N.x; r.ny = N.y; r.nz = N.z;
+        r.nA = dot(N, A);
+        r.d00 = dot(e0, e0); r.d01 = dot(e0, e1); r.d11 = dot(e1, e1);
+        r.inv_denom = 1 / (r.d00 * r.d11 - r.d01 * r.d01);
+        r.face = f;
+        r.flags = sc->materials[sc->mat_id[f]].illum == 9 ? 1u : 0u;
+        r.pad = 0u;
+    }
+    c->reflective = false;
+    for (uint32_t m = 0; m < sc->n_materials; ++m) {
+        const int il = sc->materials[m].illum;
+        if (il == 9 || il == 6 || (il > 2 && il < 6)) c->reflective = true;
+    }
+
+    free_scene(c);
+    rt_status st;
+    if ((st = upload(c, &c->d_nodes, sc->nodes, sc->n_nodes)) != RT_OK) return st;
+    if ((st = upload(c, &c->d_tris, recs.data(), recs.size())) != RT_OK) return st;
+    if ((st = upload(c, &c->d_tri_verts, sc->tri_verts, static_cast<size_t>(sc->n_faces) * 9)) != RT_OK) return st;
+    if ((st = upload(c, &c->d_face_normal, sc->face_normal, static_cast<size_t>(sc->n_faces) * 3)) != RT_OK) return st;
+    if ((st = upload(c, &c->d_tri_vid, sc->tri_vid, static_cast<size_t>(sc->n_faces) * 3)) != RT_OK) return st;
+    if ((st = upload(c, &c->d_mat_id, sc->mat_id, sc->n_faces)) != RT_OK) return st;
+    if ((st = upload(c, &c->d_vert_normal, sc->vert_normal, static_cast<size_t>(sc->n_vert_normals) * 3)) != RT_OK) return st;
+    if ((st = upload(c, &c->d_mats, sc->materials, sc->n_materials)) != RT_OK) return st;
+    c->S.nodes = static_cast<const rt_node *>(c->d_nodes);
+    c->S.leaf_tris = static_cast<const TriRec *>(c->d_tris);
+    c->S.tri_verts = static_cast<const float *>(c->d_tri_verts);
+    c->S.face_normal = static_cast<const float *>(c->d_face_normal);
+    c->S.tri_vid = static_cast<const uint32_t *>(c->d_tri_vid);
+    c->S.mat_id = static_cast<const int32_t *>(c->d_mat_id);
+    c->S.vert_normal = static_cast<const float *>(c->d_vert_normal);
+    c->S.mats = static_cast<const rt_material *>(c->d_mats);
+    std::memcpy(c->S.model, sc->model, sizeof(float) * 12);
+    c->S.n_nodes = sc->n_nodes;
+    c->S.n_faces = sc->n_faces;
+    c->has_scene = true;
+    return RT_OK;
+}
+
+extern "C" int32_t rt_local_rows(const rt_params *p) {
+    if (!p || p->stripe <= 0 || p->nranks <= 0 || p->row1 < p->row0) return 0;
+    int32_t n = 0;
+    for (int32_t y = p->row0; y < p->row1; ++y)
+        if (((y - p->row0) / p->stripe) % p->nranks == p->rank) ++n;
+    return n;
+}
+
+static rt_status check_lights(rt_ctx *c, const rt_lights *l, DLights *out) {
+    if (!l || l->n_lights < 1 || l->n_lights > RT_MAX_LIGHTS) { c->err = "lights: n_lights must be in 1..25 (the reference overflows bool[25] beyond)"; return RT_ERR_INVALID; }
+    if (l->mode != RT_LIGHT_POINT && l->mode != RT_LIGHT_AREA) { c->err = "lights: mode must be point or area (the unseeded spherical mode is out of scope)"; return RT_ERR_INVALID; }
+    int ns = 1;
+    if (l->mode == RT_LIGHT_AREA) {
+        if (l->usteps < 1 || l->vsteps < 1 || static_cast<long>(l->usteps) * l->vsteps > RT_MAX_SAMPLES) { c->err = "lights: usteps*vsteps must be in 1..1024"; return RT_ERR_INVALID; }
+        ns = l->usteps * l->vsteps;
+    }
+    std::memset(out, 0, sizeof *out);
+    std::memcpy(out->pos, l->pos, sizeof out->pos);
+    std::memcpy(out->color, l->color, sizeof out->color);
+    out->n_lights = l->n_lights; out->mode = l->mode;
+    out->usteps = l->mode == RT_LIGHT_AREA ? l->usteps : 1;
+    out->vsteps = l->mode == RT_LIGHT_AREA ? l->vsteps : 1;
+    out->n_samples = ns; out->len_x = l->len_x; out->len_y = l->len_y;
+    return RT_OK;
+}
+
+static rt_status ensure_frame(rt_ctx *c, size_t npix, int levels, size_t vis_words) {
+    if (npix > c->cap_pix || levels > c->cap_levels || vis_words > c->cap_vis) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const size_t np = npix > c->cap_pix ? npix : c->cap_pix;
+        const int lv = levels > c->cap_levels ? levels : c->cap_levels;
+        const size_t vw = vis_words > c->cap_vis ? vis_words : c->cap_vis;
+        free_frame(c);
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_rays[0]), np * sizeof(RayItem)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_rays[1]), np * sizeof(RayItem)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_items), np * sizeof(ShadeItem)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_vis), vw * sizeof(unsigned long long)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_rec), np * static_cast<size_t>(lv) * sizeof(float4)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_fres), np * static_cast<size_t>(lv) * sizeof(float)));
+        c->cap_pix = np; c->cap_levels = lv; c->cap_vis = vw;
+    }
+    return RT_OK;
+}
+
+static hipEvent_t event_at(rt_ctx *c, size_t i) {
+    while (c->events.size() <= i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->events.push_back(e);
+    }
+    return c->events[i];
+}
+
+// One frame = memset(control) ; per level { trace ; shadow ; shade } ; resolve -- no host synchronisation inside.
+static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLights &L, DFrame F, bool primary, bool count,
+                           float *d_rgb, uint8_t *d_u8, int32_t *d_hit, float *d_t, bool timed, uint32_t n_input_rays) {
+    const int D = F.max_depth;
+    // bounce levels can only be populated when some material reflects/refracts
+    const int levels_run = c->reflective ? D + 1 : 1;
+    const int lslots = L.n_lights;
+    const size_t P = (static_cast<size_t>(L.n_samples) + 63) / 64;
+    rt_status s = ensure_frame(c, F.npix, D + 1, static_cast<size_t>(F.npix) * lslots * P);
+    if (s != RT_OK) return s;
+    HIPCHK(c, hipMemsetAsync(c->d_ctl, 0, sizeof(Control), st));
+    if (!primary) HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->d_ctl->n_rays[0]), static_cast<int>(n_input_rays), 1, st));
+    const int grid = c->cus * 8;
+    size_t ev = c->ev_base;
+    DCam cam0{};
+    if (cam) cam0 = *cam;
+    if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
+    for (int level = 0; level < levels_run; ++level) {
+        float4 *rec_l = c->d_rec + static_cast<size_t>(level) * F.npix;
+        float *fres_l = c->d_fres + static_cast<size_t>(level) * F.npix;
+        const bool prim = primary && level == 0;
+        launch_trace(prim, count, grid, st, c->S, cam0, L, F, level, 3 * level, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
+                     level == 0 ? d_hit : nullptr, level == 0 ? d_t : nullptr);
+        if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
+        launch_shadow(count, grid, st, c->S, L, level, 3 * level + 1, lslots, c->d_items, c->d_ctl, c->d_vis);
+        if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
+        launch_shade(c->cus * 4, st, c->S, L, F, level, 3 * level + 2, lslots, c->d_items, c->d_ctl, c->d_vis, rec_l, fres_l, c->d_rays[(level + 1) & 1]);
+        if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
+    }
+    DFrame Fr = F;
+    Fr.max_depth = levels_run - 1;
+    launch_resolve(c->cus * 8, st, Fr, c->d_rec, c->d_fres, d_rgb, d_u8);
+    if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
+    HIPCHK(c, hipGetLastError());
+    return RT_OK;
+}
+
+static rt_status sum_frame_times(rt_ctx *c, size_t ev, int levels_run, rt_stats *out) {
+    float ms = 0.f;
+    const size_t first = ev;
+    for (int level = 0; level < levels_run; ++level) {
+        HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_trace += ms; ++ev;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_shadow += ms; ++ev;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_shade += ms; ++ev;
+    }
+    HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_resolve += ms;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->events[first], c->events[ev + 1])); out->ms_total += ms;
+    out->launches_trace += static_cast<uint32_t>(levels_run);
+    out->launches_shadow += static_cast<uint32_t>(levels_run);
+    out->launches_shade += static_cast<uint32_t>(levels_run);
+    return RT_OK;
+}
+
+static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int levels_run, bool timed, rt_stats *out, bool counted) {
+    HIPCHK(c, hipStreamSynchronize(st));
+    Control h;
+    HIPCHK(c, hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
+    out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample;
+    out->pixels = F.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;
+    if (counted) {
+        out->box_tests = h.box_tests + h.box_tests_shadow; out->leaf_tri_refs = h.leaf_tri_refs + h.leaf_tri_refs_shadow;
+        out->box_tests_shadow = h.box_tests_shadow; out->leaf_tri_refs_shadow = h.leaf_tri_refs_shadow;
+    }
+    if (timed) {
+        out->ms_trace = out->ms_shadow = out->ms_shade = out->ms_resolve = out->ms_total = 0.f;
+        out->launches_trace = out->launches_shadow = out->launches_shade = 0;
+        rt_status s = sum_frame_times(c, c->ev_base, levels_run, out);
+        if (s != RT_OK) return s;
+    }
+    return RT_OK;
+}
+
+static rt_status make_frame(rt_ctx *c, const rt_params *p, DFrame *F) {
+    if (!p || p->width <= 0 || p->height <= 0) { c->err = "params: width/height must be positive"; return RT_ERR_INVALID; }
+    if (p->stripe <= 0 || p->nranks <= 0 || p->rank < 0 || p->rank >= p->nranks || p->row0 < 0 || p->row1 > p->height || p->row0 > p->row1) {
+        c->err = "params: bad row shard (row0,row1,stripe,rank,nranks)";
+        return RT_ERR_INVALID;
+    }
+    if (p->max_depth > RT_MAX_DEPTH) { c->err = "params: max_depth above RT_MAX_DEPTH"; return RT_ERR_UNSUPPORTED; }
+    F->width = p->width; F->height = p->height;
+    F->local_rows = rt_local_rows(p);
+    F->row0 = p->row0; F->stripe = p->stripe; F->rank = p->rank; F->nranks = p->nranks;
+    F->tiles_x = (p->width + 7) / 8; F->tiles_y = (F->local_rows + 7) / 8;
+    F->npix = static_cast<uint32_t>(F->local_rows) * static_cast<uint32_t>(p->width);
+    F->max_depth = p->max_depth < 0 ? RT_MAX_DEPTH : p->max_depth;
+    return RT_OK;
+}
+
+static void make_cam(const rt_camera *cam, DCam *d) {
+    std::memcpy(d->center, cam->center, sizeof d->center);
+    std::memcpy(d->inv_view, cam->inv_view, sizeof d->inv_view);
+    std::memcpy(d->vp, cam->viewport, sizeof d->vp);
+    // getPerspectiveScale / scale (camera.hpp:164-166, 263-266): host double arithmetic, as the reference
+    const float persp = static_cast<float>(static_cast<double>(1.0f) / std::tan(static_cast<double>(cam->fovy / 2.0f) * (M_PI / static_cast<double>(180.0f))));
+    const float scale = static_cast<float>(1.0 / static_cast<double>(persp));
+    d->k0 = cam->aspect * scale;
+    d->k1 = scale;
+}
+
+extern "C" rt_status rt_render_device(rt_ctx *c, const rt_camera *cam, const rt_lights *lights, const rt_params *p,
+                                      float *d_out_rgb, uint8_t *d_out_u8, int32_t *d_out_hit, void *stream, rt_stats *stats) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->has_scene) { c->err = "render before rt_upload_scene"; return RT_ERR_NO_SCENE; }
+    if (!cam) { c->err = "camera is null"; return RT_ERR_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    DLights L;
+    rt_status s = check_lights(c, lights, &L);
+    if (s != RT_OK) return s;
+    DFrame F;
+    if ((s = make_frame(c, p, &F)) != RT_OK) return s;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (F.npix == 0) return RT_OK;
+    DCam dc;
+    make_cam(cam, &dc);
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    const int levels_run = c->reflective ? F.max_depth + 1 : 1;
+    if (stats && p->collect_stats == 1) {
+        // counting pass: same frame with the no-early-out traversal variants (never part of a timed region)
+        if ((s = run_frame(c, st, &dc, L, F, true, true, d_out_rgb, d_out_u8, d_out_hit, nullptr, false, 0)) != RT_OK) return s;
+        if ((s = fill_stats(c, st, F, levels_run, false, stats, true)) != RT_OK) return s;
+    }
+    if (p->collect_stats == 2) {
+        const size_t first = c->ev_base;
+        if ((s = run_frame(c, st, &dc, L, F, true, false, d_out_rgb, d_out_u8, d_out_hit, nullptr, true, 0)) != RT_OK) return s;
+        c->pending.emplace_back(first, levels_run);
+        c->ev_base = first + static_cast<size_t>(3 * levels_run + 2);
+        c->pending_stream = st;
+        c->pending_frame = F;
+        return RT_OK;
+    }
+    if ((s = run_frame(c, st, &dc, L, F, true, false, d_out_rgb, d_out_u8, d_out_hit, nullptr, stats != nullptr, 0)) != RT_OK) return s;
+    if (stats) {
+        const uint64_t bt = stats->box_tests, lr = stats->leaf_tri_refs, bts = stats->box_tests_shadow, lrs = stats->leaf_tri_refs_shadow;
+        if ((s = fill_stats(c, st, F, levels_run, true, stats, false)) != RT_OK) return s;
+        stats->box_tests = bt; stats->leaf_tri_refs = lr; stats->box_tests_shadow = bts; stats->leaf_tri_refs_shadow = lrs;
+    }
+    return RT_OK;
+}
+
+extern "C" rt_status rt_timing_collect(rt_ctx *c, rt_stats *out) {
+    if (!c || !out) return RT_ERR_INVALID;
+    std::memset(out, 0, sizeof *out);
+    if (c->pending.empty()) return RT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->pending_stream));
+    Control h;
+    HIPCHK(c, hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
+    out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample;
+    out->pixels = c->pending_frame.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;
+    rt_status s = RT_OK;
+    for (const auto &fr : c->pending)
+        if ((s = sum_frame_times(c, fr.first, fr.second, out)) != RT_OK) break;
+    c->pending.clear();
+    c->ev_base = 0;
+    return s;
+}
+
+extern "C" rt_status rt_render(rt_ctx *c, const rt_camera *cam, const rt_lights *lights, const rt_params *p,
+                               float *out_rgb, int32_t *out_hit, rt_stats *stats) {
+    if (!c) return RT_ERR_INVALID;
+    if (!out_rgb || !p) { c->err = "rt_render: null output or params"; return RT_ERR_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npix = static_cast<size_t>(rt_local_rows(p)) * static_cast<size_t>(p->width > 0 ? p->width : 0);
+    if (npix > c->cap_out) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_rgb) (void)hipFree(c->d_rgb);
+        if (c->d_hit) (void)hipFree(c->d_hit);
+        if (c->d_t) (void)hipFree(c->d_t);
+        c->d_rgb = nullptr; c->d_hit = nullptr; c->d_t = nullptr; c->cap_out = 0;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_rgb), npix * 3 * sizeof(float)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_hit), npix * sizeof(int32_t)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_t), npix * sizeof(float)));
+        c->cap_out = npix;
+    }
+    rt_status s = rt_render_device(c, cam, lights, p, c->d_rgb, nullptr, out_hit ? c->d_hit : nullptr, nullptr, stats);
+    if (s != RT_OK) return s;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (npix) {
+        HIPCHK(c, hipMemcpy(out_rgb, c->d_rgb, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        if (out_hit) HIPCHK(c, hipMemcpy(out_hit, c->d_hit, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    return RT_OK;
+}
+
+extern "C" rt_status rt_trace_rays(rt_ctx *c, const rt_lights *lights, int32_t max_depth, int32_t n, const float *origin,
+                                   const float *dir, float *out_rgb, int32_t *out_face, float *out_t) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->has_scene) { c->err = "rt_trace_rays before rt_upload_scene"; return RT_ERR_NO_SCENE; }
+    if (n < 0 || (n && (!origin || !dir || !out_rgb))) { c->err = "rt_trace_rays: bad arguments"; return RT_ERR_INVALID; }
+    if (max_depth > RT_MAX_DEPTH) { c->err = "rt_trace_rays: max_depth above RT_MAX_DEPTH"; return RT_ERR_UNSUPPORTED; }
+    if (n == 0) return RT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    DLights L;
+    rt_status s = check_lights(c, lights, &L);
+    if (s != RT_OK) return s;
+    DFrame F{};
+    F.width = n; F.height = 1; F.local_rows = 1; F.row0 = 0; F.stripe = 1; F.rank = 0; F.nranks = 1;
+    F.tiles_x = (n + 7) / 8; F.tiles_y = 1; F.npix = static_cast<uint32_t>(n);
+    F.max_depth = max_depth < 0 ? RT_MAX_DEPTH : max_depth;
+    const size_t P = (static_cast<size_t>(L.n_samples) + 63) / 64;
+    if ((s = ensure_frame(c, F.npix, F.max_depth + 1, static_cast<size_t>(F.npix) * L.n_lights * P)) != RT_OK) return s;
+    std::vector<RayItem> rays(static_cast<size_t>(n));
+    for (int32_t i = 0; i < n; ++i) {
+        RayItem &r = rays[static_cast<size_t>(i)];
+        r.ox = origin[i * 3]; r.oy = origin[i * 3 + 1]; r.oz = origin[i * 3 + 2];
+        r.dx = dir[i * 3]; r.dy = dir[i * 3 + 1]; r.dz = dir[i * 3 + 2];
+        r.lx = r.ly = r.lz = 0.f; r.lmode = 0u; r.pix = static_cast<uint32_t>(i); r.pad = 0u;
+    }
+    const size_t need = static_cast<size_t>(n);
+    if (need > c->cap_out) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_rgb) (void)hipFree(c->d_rgb);
+        if (c->d_hit) (void)hipFree(c->d_hit);
+        if (c->d_t) (void)hipFree(c->d_t);
+        c->d_rgb = nullptr; c->d_hit = nullptr; c->d_t = nullptr; c->cap_out = 0;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_rgb), need * 3 * sizeof(float)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_hit), need * sizeof(int32_t)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_t), need * sizeof(float)));
+        c->cap_out = need;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_rays[0], rays.data(), need * sizeof(RayItem), hipMemcpyHostToDevice, c->stream));
+    if ((s = run_frame(c, c->stream, nullptr, L, F, false, false, c->d_rgb, nullptr, c->d_hit, c->d_t, false, static_cast<uint32_t>(n))) != RT_OK) return s;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out_rgb, c->d_rgb, need * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_face) HIPCHK(c, hipMemcpy(out_face, c->d_hit, need * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (out_t) HIPCHK(c, hipMemcpy(out_t, c->d_t, need * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" rt_status rt_light_strikes(rt_ctx *c, int32_t n, const float *hit, const float *light, uint8_t *vis) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->has_scene) { c->err = "rt_light_strikes before rt_upload_scene"; return RT_ERR_NO_SCENE; }
+    if (n < 0 || (n && (!hit || !light || !vis))) { c->err = "rt_light_strikes: bad arguments"; return RT_ERR_INVALID; }
+    if (n == 0) return RT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    float *d_hit = nullptr, *d_light = nullptr;
+    uint8_t *d_vis = nullptr;
+    const size_t bytes = static_cast<size_t>(n) * 3 * sizeof(float);
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&d_hit), bytes));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&d_light), bytes));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&d_vis), static_cast<size_t>(n)));
+    rt_status s = RT_OK;
+    do {
+        if (hipMemcpy(d_hit, hit, bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_light, light, bytes, hipMemcpyHostToDevice) != hipSuccess) { s = RT_ERR_HIP; c->err = "rt_light_strikes: upload failed"; break; }
+        const int blocks = (n + 255) / 256;
+        launch_segments(blocks < c->cus * 8 ? blocks : c->cus * 8, c->stream, c->S, n, d_hit, d_light, d_vis);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(vis, d_vis, static_cast<size_t>(n), hipMemcpyDeviceToHost) != hipSuccess) { s = RT_ERR_HIP; c->err = "rt_light_strikes: kernel or download failed"; break; }
+    } while (0);
+    (void)hipFree(d_hit); (void)hipFree(d_light); (void)hipFree(d_vis);
+    return s;
+}
+
+// ---- host scene wrappers ------------------------------------------------------------------------------------
+extern "C" rt_status rt_host_scene_load(const char *obj_path, int32_t leaf_capacity, int32_t max_depth, rt_host_scene **out) {
+    if (!obj_path || !out || leaf_capacity < 1 || max_depth < 0 || max_depth > 15) return RT_ERR_INVALID;
+    *out = nullptr;
+    rt_host_scene *h = new rt_host_scene();
+    std::string err;
+    if (!h->hs.load_obj(obj_path, &err)) {
+        std::fprintf(stderr, "rt_mi355x: %s\n", err.c_str());
+        delete h;
+        return RT_ERR_IO;
+    }
+    h->hs.build_octree(leaf_capacity, max_depth);
+    h->hs.flatten();
+    *out = h;
+    return RT_OK;
+}
+
+extern "C" void rt_host_scene_free(rt_host_scene *hs) { delete hs; }
+
+extern "C" rt_status rt_host_scene_view(const rt_host_scene *hs, rt_scene *out) {
+    if (!hs || !out) return RT_ERR_INVALID;
+    hs->hs.view(out);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_host_scene_set_model(rt_host_scene *hs, const float model[12], int32_t rebuild_tree) {
+    if (!hs || !model) return RT_ERR_INVALID;
+    hs->hs.set_model(model, rebuild_tree != 0);
+    return RT_OK;
+}
+
+extern "C" rt_status rt_host_scene_info(const rt_host_scene *hs, int32_t out[8], float root_box[6]) {
+    if (!hs || !out) return RT_ERR_INVALID;
+    hs->hs.info(out, root_box);
+    return RT_OK;
+}
+
+extern "C" void rt_default_camera(rt_camera *cam, int32_t w, int32_t h) { if (cam && w > 0 && h > 0) default_camera(cam, w, h); }
+extern "C" void rt_yaw_camera(rt_camera *cam, int32_t w, int32_t h, float yaw) { if (cam && w > 0 && h > 0) yaw_camera(cam, w, h, yaw); }
+extern "C" void rt_screen_to_world(const rt_camera *cam, float i, float j, float out[3]) { if (cam && out) screen_to_world(cam, i, j, out); }
+extern "C" void rt_default_lights(rt_lights *l, int32_t area) { if (l) default_lights(l, area); }
+
+extern "C" rt_status rt_write_ppm(const char *path, const float *rgb, int32_t w, int32_t h) {
+    if (!path || !rgb || w <= 0 || h <= 0) return RT_ERR_INVALID;
+    return write_ppm(path, rgb, w, h) ? RT_OK : RT_ERR_IO;
+}
+extern "C" rt_status rt_write_ppm_u8(const char *path, const uint8_t *rgb, int32_t w, int32_t h) {
+    if (!path || !rgb || w <= 0 || h <= 0) return RT_ERR_INVALID;
+    return write_ppm_u8(path, rgb, w, h) ? RT_OK : RT_ERR_IO;
+}

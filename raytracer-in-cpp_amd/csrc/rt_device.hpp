@@ -1,0 +1,115 @@
+// rt_device.hpp -- device-side data layout shared by the HIP kernels and the C-ABI host code.
+//
+// HBM layout (all arrays resident for the lifetime of the uploaded scene; 288 GB per MI355X makes the
+// per-frame working buffers -- one slot per pixel per recursion level -- a non-issue):
+//   nodes      rt_node[n_nodes]        32 B   breadth-first, live children contiguous, read wave-uniformly (s_load)
+//   leaf_tris  TriRec[n_face_refs]     80 B   leaf-ordered, per-triangle constants of rayTriangleIntersection
+//                                             hoisted (bit-identical float ops evaluated once on the host)
+//   tri_verts / face_normal / tri_vid / mat_id / vert_normal / mats   shading inputs, gathered per shaded hit
+//   rays[2]    RayItem[npix]           48 B   ping-pong bounce rays (level >= 1), compacted per level
+//   items      ShadeItem[npix]         64 B   lit closest hits of the current level (compacted)
+//   vis        u64[npix * L * words]          sample-visibility masks written by the shadow kernel
+//   rec        float4[(D+1) * npix]           per pixel, per level: Phong RGB + blend kind (folded by resolve)
+//   fres       float [(D+1) * npix]           Fresnel factor of illum-5 hits
+#pragma once
+
+#include <cstdint>
+
+#include "rt_mi355x.h"
+
+namespace rtamd {
+
+// Per-(leaf, triangle) record, 80 B = s_load_dwordx16 + s_load_dwordx4.  Everything here is a pure function of
+// the triangle that Flyscene::rayTriangleIntersection (flyscene.cpp:787-819) recomputes on every call.
+struct alignas(16) TriRec {
+    float ax, ay, az;        // vertices[0]
+    float e0x, e0y, e0z;     // v0 = vertices[2] - vertices[0]
+    float e1x, e1y, e1z;     // v1 = vertices[1] - vertices[0]
+    float nx, ny, nz;        // triangle.normal
+    float nA;                // triangleNormal.dot(vertices[0])
+    float d00, d01, d11;     // v0.v0, v0.v1, v1.v1
+    float inv_denom;         // 1 / (d00*d11 - d01*d01)
+    uint32_t face;           // face id (tie-break: lowest id wins, std::set order + strict '<')
+    uint32_t flags;          // bit 0: material illum == 9 (skipped by lightStrikes, flyscene.cpp:934-936)
+    uint32_t pad;
+};
+static_assert(sizeof(TriRec) == 80, "TriRec must be 80 bytes");
+
+struct alignas(16) RayItem {     // a bounce ray (level >= 1) or an rt_trace_rays input ray
+    float ox, oy, oz, dx;
+    float dy, dz, lx, ly;
+    float lz;
+    uint32_t lmode;              // 0: sees the scene lights; 1: sees the single light (lx,ly,lz) (flyscene.cpp:735-738)
+    uint32_t pix;
+    uint32_t pad;
+};
+static_assert(sizeof(RayItem) == 48, "RayItem must be 48 bytes");
+
+struct alignas(16) ShadeItem {   // a lit closest hit waiting for its sample shadow rays and Phong
+    float ox, oy, oz, dx;
+    float dy, dz, lx, ly;
+    float lz;
+    uint32_t lmode;
+    uint32_t pix;
+    int32_t face;
+    float t;
+    uint32_t pad0, pad1, pad2;
+};
+static_assert(sizeof(ShadeItem) == 64, "ShadeItem must be 64 bytes");
+
+// blend kinds stored in rec[].w (bit pattern of a uint32)
+enum : uint32_t {
+    KIND_CONST = 0,      // terminal: rgb is the value (BACKGROUND, SHADOW or plain Phong)
+    KIND_PASS = 1,       // illum 9:      0.10*phong + 0.90*child   (flyscene.cpp:718)
+    KIND_REFRACT = 2,    // illum 6:      0.2*phong  + 0.8*child    (flyscene.cpp:754)
+    KIND_MIRROR = 3,     // illum 3,4:    0.15*phong + 0.85*child   (flyscene.cpp:738)
+    KIND_FRESNEL = 4     // illum 5:      fresnel * (0.15*phong + 0.85*child)  (flyscene.cpp:739-743)
+};
+
+struct DScene {
+    const rt_node *nodes;
+    const TriRec *leaf_tris;
+    const float *tri_verts;
+    const float *face_normal;
+    const uint32_t *tri_vid;
+    const int32_t *mat_id;
+    const float *vert_normal;
+    const rt_material *mats;
+    float model[12];
+    uint32_t n_nodes, n_faces;
+};
+
+struct DCam {
+    float center[3];
+    float inv_view[12];
+    float vp[4];
+    float k0, k1;            // aspect*scale, scale  (camera.hpp:164-166), evaluated on the host
+};
+
+struct DLights {
+    float pos[RT_MAX_LIGHTS][3];
+    float color[3];
+    int32_t n_lights, mode, usteps, vsteps, n_samples;
+    float len_x, len_y;
+};
+
+struct DFrame {              // which pixels this launch covers
+    int32_t width, height;   // full frame
+    int32_t local_rows;      // rows rendered by this shard
+    int32_t row0, stripe, rank, nranks;
+    int32_t tiles_x, tiles_y;
+    uint32_t npix;           // local_rows * width
+    int32_t max_depth;
+};
+
+// control block in device memory (zeroed once per frame by a memset node on the render stream)
+struct Control {
+    uint32_t tile_ctr[3 * (RT_MAX_DEPTH + 1) + 4];   // one work-queue head per launch
+    uint32_t n_items[RT_MAX_DEPTH + 1];              // lit hits per level
+    uint32_t n_rays[RT_MAX_DEPTH + 2];               // bounce rays per level (n_rays[0] = rt_trace_rays input count)
+    unsigned long long rays_primary, rays_bounce, rays_centre, rays_sample, pixels_culled, shaded_hits;
+    unsigned long long box_tests, leaf_tri_refs;              // k_trace (closest hit + light-centre rays)
+    unsigned long long box_tests_shadow, leaf_tri_refs_shadow; // k_shadow (area-light sample rays)
+};
+
+}  // namespace rtamd

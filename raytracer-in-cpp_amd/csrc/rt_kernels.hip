@@ -1,0 +1,628 @@
+// rt_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for the primary/shadow ray-trace path.
+//
+// Execution model (designed for 64-wide wavefronts + the scalar unit, not a port of a lane-per-ray CPU loop):
+//   * PACKET TRAVERSAL.  One wavefront owns 64 coherent rays (an 8x8 pixel tile, 64 compacted bounce rays, or the
+//     N area-light samples of one hit point).  The octree walk is WAVE-UNIFORM: node ids and per-node lane masks
+//     live in a small per-wave LDS stack, node boxes and leaf triangle records are fetched with scalar loads
+//     (s_load_dwordx8/x16 through the scalar cache -- no VGPR gather, no per-lane addressing), and each lane only
+//     runs the arithmetic for its own ray under an exec mask.  `__ballot` decides whether any lane still needs a
+//     child / a leaf.  This reproduces BoxTree::intersect's result exactly (src/boxTree.cpp:150-173: a lane's
+//     candidate set = faces of every non-empty leaf whose whole ancestor chain its ray's box tests accept) while
+//     touching each node/triangle once per wave instead of once per ray.
+//   * PERSISTENT WAVES.  Every kernel is launched with a fixed grid; waves pull tiles from a device-side queue
+//     head (one returning atomicAdd per tile).  Work sizes that depend on earlier kernels (lit hits, bounce
+//     rays) are read from device memory, so a whole frame is a fixed launch sequence with no host round trip
+//     and can be captured in a hipGraph.
+//   * Shadow samples are a SEPARATE kernel (k_shadow) so rocprof attributes traversal time to
+//     closest-hit (k_trace) vs area-light shadow rays (k_shadow) separately.
+//   * Ray compaction between bounces uses wave-wide ballot + mbcnt prefix and one atomicAdd per wave.
+//
+// Numerics: compiled with -ffp-contract=off and correctly rounded fp32 divide/sqrt; every expression keeps the
+// reference's operation order (Eigen 3.3.7: a.dot(b) = a0*b0 + (a1*b1 + a2*b2)), std::min/std::max are spelt as
+// the ternaries libstdc++ uses, so integer results (face ids, 8-bit pixels) are bit-exact and float RGB differs
+// from the CPU path only through powf (evaluated here in double precision and rounded once).
+#include <hip/hip_runtime.h>
+
+#include "rt_device.hpp"
+
+namespace rtamd {
+
+#define RT_WAVES 4          // waves per workgroup (256 threads)
+#define RT_STACK 128        // >= 7*16 + 8: DFS stack bound for MAX_DEPTH 15 octrees (checked on upload)
+
+// ---- libstdc++ std::min / std::max (NaN behaviour is part of the reference's slab test) -----------------------
+__device__ __forceinline__ float smin(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float smax(float a, float b) { return (a < b) ? b : a; }
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return ax * bx + (ay * by + az * bz);
+}
+__device__ __forceinline__ void normalize3(float &x, float &y, float &z) {
+    const float q = x * x + (y * y + z * z);
+    if (q > 0.0f) {
+        const float s = sqrtf(q);
+        x = x / s; y = y / s; z = z / s;
+    }
+}
+
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+}
+
+// BoundingBox::boxIntersect (src/boundingBox.cpp:48-83) with dir = dest - origin already formed by the caller.
+__device__ __forceinline__ bool box_hit(const float *__restrict__ b, float ox, float oy, float oz, float dx, float dy, float dz) {
+    const float tx0 = (b[0] - ox) / dx, tx1 = (b[3] - ox) / dx;
+    const float ty0 = (b[1] - oy) / dy, ty1 = (b[4] - oy) / dy;
+    const float tz0 = (b[2] - oz) / dz, tz1 = (b[5] - oz) / dz;
+    const float tin = smax(smax(smin(tx0, tx1), smin(ty0, ty1)), smin(tz0, tz1));
+    const float tout = smin(smin(smax(tx0, tx1), smax(ty0, ty1)), smax(tz0, tz1));
+    return !((tin > tout) || (tout < 0));
+}
+
+struct WaveStack {
+    uint32_t *node;
+    unsigned long long *mask;
+};
+
+// Wave-uniform octree walk for 64 rays.
+//   ANY   = false: closest hit (flyscene.cpp:675-683): min t over candidates with t > 1e-5, ties to the lowest
+//                  face id.  No t-ordered pruning: the reference tests every triangle of every intersected leaf,
+//                  and because its tree loses/misfiles triangles a pruned walk would not be equivalent.
+//   ANY   = true : lightStrikes (flyscene.cpp:912-954): visible iff min t >= 0.98, i.e. occluded iff SOME candidate
+//                  (not illum 9) has 1e-5 < t < 0.98 -- so a lane may stop at its first occluder (exact).
+//   COUNT = true : no early-out; counts boxIntersect calls / leaf face references with the reference's semantics
+//                  (every pushed node is box-tested again when popped, boxTree.cpp:158,164).
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void packet_walk(const DScene &S, const WaveStack stk, const int lane, bool in_root,
+                                            const float ox, const float oy, const float oz,      // ray origin
+                                            const float dx, const float dy, const float dz,      // triangle-test direction
+                                            const float bx, const float by, const float bz,      // box-test direction (dest - origin)
+                                            float &best_t, int &best_f, bool &occluded,
+                                            uint32_t &cnt_box, uint32_t &cnt_ref) {
+    int sp = 0;
+    {
+        const unsigned long long m0 = __ballot(in_root);
+        if (m0 == 0ull) return;
+        if (COUNT && in_root) cnt_box += 1;      // BoxTree::intersect re-tests the root it was just given
+        stk.node[0] = 0u;
+        stk.mask[0] = m0;
+        sp = 1;
+    }
+    while (sp > 0) {
+        --sp;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t ni = uniform_u32(stk.node[sp]);
+        const unsigned long long m = uniform_u64(stk.mask[sp]);
+        bool mine = ((m >> lane) & 1ull) != 0ull;
+        if (ANY && !COUNT) {
+            mine = mine && !occluded;
+            if (__ballot(mine) == 0ull) continue;
+        }
+        const rt_node nd = S.nodes[ni];
+        const uint32_t cnt = nd.count_flags & 0x7fffffffu;
+        if (nd.count_flags & RT_NODE_LEAF) {
+            if (COUNT && mine) cnt_ref += cnt;
+            const TriRec *__restrict__ T = S.leaf_tris + nd.first;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const TriRec tr = T[k];                       // wave-uniform address: scalar loads
+                if (mine && !(ANY && (tr.flags & 1u))) {
+                    // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819
+                    const float dn = dot3(dx, dy, dz, tr.nx, tr.ny, tr.nz);
+                    if (dn != 0) {
+                        const float t = (tr.nA - dot3(ox, oy, oz, tr.nx, tr.ny, tr.nz)) / dn;
+                        const float v2x = (ox + t * dx) - tr.ax, v2y = (oy + t * dy) - tr.ay, v2z = (oz + t * dz) - tr.az;
+                        const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
+                        const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
+                        const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
+                        const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
+                        if ((u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f)) {
+                            if (ANY) {
+                                if (t < 0.98f) occluded = true;
+                            } else if (t < best_t || (t == best_t && static_cast<int>(tr.face) < best_f)) {
+                                best_t = t;
+                                best_f = static_cast<int>(tr.face);
+                            }
+                        }
+                    }
+                }
+                if (ANY && !COUNT && (k & 7u) == 7u) {
+                    mine = mine && !occluded;
+                    if (__ballot(mine) == 0ull) break;
+                }
+            }
+        } else {
+            for (uint32_t c = 0; c < cnt; ++c) {
+                const uint32_t ci = nd.first + c;
+                const rt_node ch = S.nodes[ci];
+                const bool h = mine && box_hit(ch.bmin, ox, oy, oz, bx, by, bz);
+                if (COUNT && mine) cnt_box += h ? 2u : 1u;
+                const unsigned long long hm = __ballot(h);
+                if (hm != 0ull) {
+                    stk.node[sp] = ci;           // same value from every lane
+                    stk.mask[sp] = hm;
+                    ++sp;
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// arealight::getPointLights / createSpherePoint (arealight.hpp:15-25, flyscene.cpp:956-972): sample s of light p
+__device__ __forceinline__ void light_sample(const DLights &L, const float px, const float py, const float pz, const int s,
+                                             float &sx, float &sy, float &sz) {
+    if (L.mode == RT_LIGHT_POINT) { sx = px; sy = py; sz = pz; return; }
+    const float ux = px + L.len_x * 1.0f;     // uvec = corner + lengthX * (1,0,0)
+    const float uz = pz + L.len_x * 0.0f;
+    const float vy = py + L.len_y * 1.0f;     // vvec = corner + lengthY * (0,1,0)
+    const int i = s / L.vsteps, j = s - i * L.vsteps;
+    sx = (static_cast<float>(i) + 0.5f) * (ux / static_cast<float>(L.usteps));
+    sy = (static_cast<float>(j) + 0.5f) * (vy / static_cast<float>(L.vsteps));
+    sz = uz;
+}
+
+// ======================================================================================================
+// K1: closest hit + light-centre visibility.  PRIMARY: fused primary-ray generation (Camera::screenToWorld)
+// and root-AABB cull of raytraceScene's serial loop (flyscene.cpp:573-598); otherwise reads compacted rays.
+// ======================================================================================================
+template <bool PRIMARY, bool COUNT>
+__global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const DScene S, const DCam cam, const DLights L, const DFrame F,
+                                                          const int level, const int ctr_slot,
+                                                          const RayItem *__restrict__ rays_in, ShadeItem *__restrict__ items,
+                                                          Control *__restrict__ ctl, float4 *__restrict__ rec,
+                                                          int32_t *__restrict__ out_hit, float *__restrict__ out_t) {
+    __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
+    __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK};
+    const uint32_t n_in = PRIMARY ? 0u : ctl->n_rays[level];
+    const uint32_t ntiles = PRIMARY ? static_cast<uint32_t>(F.tiles_x) * static_cast<uint32_t>(F.tiles_y) : (n_in + 63u) / 64u;
+    const rt_node root = S.nodes[0];
+
+    uint32_t c_rays = 0, c_cull = 0, c_centre = 0, c_box = 0, c_ref = 0;
+    for (;;) {
+        uint32_t tile = 0;
+        if (lane == 0) tile = atomicAdd(&ctl->tile_ctr[ctr_slot], 1u);
+        tile = uniform_u32(tile);
+        if (tile >= ntiles) break;
+
+        bool valid;
+        uint32_t pix = 0, lmode = 0;
+        float ox, oy, oz, dx, dy, dz, lx = 0.f, ly = 0.f, lz = 0.f;
+        bool in_root;
+        if (PRIMARY) {
+            const int tx = static_cast<int>(tile % static_cast<uint32_t>(F.tiles_x)), ty = static_cast<int>(tile / static_cast<uint32_t>(F.tiles_x));
+            const int x = tx * 8 + (lane & 7), lr = ty * 8 + (lane >> 3);
+            valid = (x < F.width) && (lr < F.local_rows);
+            const int y = F.row0 + ((lr / F.stripe) * F.nranks + F.rank) * F.stripe + (lr % F.stripe);
+            pix = static_cast<uint32_t>(lr) * static_cast<uint32_t>(F.width) + static_cast<uint32_t>(x);
+            // Camera::screenToWorld, camera.hpp:155-173: raster -> [-1,1] in double, cast, perspective scale, inverse view
+            const float fi = static_cast<float>(x), fj = static_cast<float>(y);
+            float n0 = static_cast<float>(2.0 * static_cast<double>(fi - cam.vp[0]) / static_cast<double>(cam.vp[2]) - 1.0);
+            float n1 = static_cast<float>(1.0 - 2.0 * static_cast<double>(fj - cam.vp[1]) / static_cast<double>(cam.vp[3]));
+            const float n2 = -1.0f;
+            n0 = n0 * cam.k0;
+            n1 = n1 * cam.k1;
+            const float *m = cam.inv_view;
+            const float sx = ((m[0] * n0 + m[1] * n1) + m[2] * n2) + m[3] * 1.0f;
+            const float sy = ((m[4] * n0 + m[5] * n1) + m[6] * n2) + m[7] * 1.0f;
+            const float sz = ((m[8] * n0 + m[9] * n1) + m[10] * n2) + m[11] * 1.0f;
+            ox = cam.center[0]; oy = cam.center[1]; oz = cam.center[2];
+            dx = sx - ox; dy = sy - oy; dz = sz - oz;          // direction = screen - origin (UNNORMALISED), flyscene.cpp:619
+            const bool pre = valid && box_hit(root.bmin, ox, oy, oz, dx, dy, dz);   // flyscene.cpp:576
+            c_cull += (valid && !pre) ? 1u : 0u;
+            in_root = pre;
+        } else {
+            const uint32_t r = tile * 64u + static_cast<uint32_t>(lane);
+            valid = r < n_in;
+            const RayItem it = rays_in[valid ? r : 0u];
+            ox = it.ox; oy = it.oy; oz = it.oz; dx = it.dx; dy = it.dy; dz = it.dz;
+            lx = it.lx; ly = it.ly; lz = it.lz; lmode = it.lmode; pix = it.pix;
+            in_root = valid;
+        }
+        c_rays += in_root ? 1u : 0u;
+        // traceRay: boxIntersect(origin, origin + direction) -- the box-test direction is (o + d) - o (flyscene.cpp:655)
+        const float bx = (ox + dx) - ox, by = (oy + dy) - oy, bz = (oz + dz) - oz;
+        if (COUNT && in_root) c_box += 1;
+        in_root = in_root && box_hit(root.bmin, ox, oy, oz, bx, by, bz);
+
+        float best_t = 3.402823466e+38f;
+        int best_f = -1;
+        bool dummy = false;
+        packet_walk<false, COUNT>(S, stk, lane, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz, best_t, best_f, dummy, c_box, c_ref);
+        const bool hit = valid && (best_f >= 0);
+        const float hx = ox + best_t * dx, hy = oy + best_t * dy, hz = oz + best_t * dz;   // flyscene.cpp:695
+
+        // lightStrikes(hitPoint, lights): one segment per light CENTRE (flyscene.cpp:700)
+        bool lit = false;
+        const int nl_lane = lmode ? 1 : L.n_lights;
+        const int nl_wave = (__ballot(hit && lmode == 0u) != 0ull) ? L.n_lights : 1;
+        if (__ballot(hit) != 0ull) {
+            for (int l = 0; l < nl_wave; ++l) {
+                const bool act = hit && (l < nl_lane);
+                const float px = lmode ? lx : L.pos[l][0], py = lmode ? ly : L.pos[l][1], pz = lmode ? lz : L.pos[l][2];
+                const float sdx = hx - px, sdy = hy - py, sdz = hz - pz;      // direction = hitPoint - origin
+                c_centre += act ? 1u : 0u;
+                if (COUNT && act) c_box += 1;
+                const bool sroot = act && box_hit(root.bmin, px, py, pz, sdx, sdy, sdz);
+                float t_unused = 0.f; int f_unused = -1;
+                bool occ = false;
+                packet_walk<true, COUNT>(S, stk, lane, sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz, t_unused, f_unused, occ, c_box, c_ref);
+                lit = lit || (act && !occ);
+            }
+        }
+
+        if (valid) {
+            if (!hit) rec[pix] = make_float4(1.f, 1.f, 1.f, __uint_as_float(KIND_CONST));          // BACKGROUND
+            else if (!lit) rec[pix] = make_float4(0.f, 0.f, 0.f, __uint_as_float(KIND_CONST));     // SHADOW
+            if (out_hit) out_hit[pix] = hit ? best_f : -1;
+            if (out_t) out_t[pix] = hit ? best_t : -1.0f;
+        }
+        // compaction: lit hits -> shade list (wave ballot + prefix, one atomic per wave)
+        const unsigned long long lm = __ballot(lit);
+        if (lm != 0ull) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&ctl->n_items[level], static_cast<uint32_t>(__popcll(lm)));
+            base = uniform_u32(base);
+            if (lit) {
+                ShadeItem o;
+                o.ox = ox; o.oy = oy; o.oz = oz; o.dx = dx; o.dy = dy; o.dz = dz;
+                o.lx = lx; o.ly = ly; o.lz = lz; o.lmode = lmode; o.pix = pix; o.face = best_f; o.t = best_t;
+                o.pad0 = o.pad1 = o.pad2 = 0u;
+                items[base + lanes_below(lm)] = o;
+            }
+        }
+    }
+    // per-wave counters -> control block
+    c_rays = wave_sum(c_rays); c_cull = wave_sum(c_cull); c_centre = wave_sum(c_centre);
+    if (COUNT) { c_box = wave_sum(c_box); c_ref = wave_sum(c_ref); }
+    if (lane == 0) {
+        if (c_rays) atomicAdd((PRIMARY || level == 0) ? &ctl->rays_primary : &ctl->rays_bounce, static_cast<unsigned long long>(c_rays));
+        if (c_cull) atomicAdd(&ctl->pixels_culled, static_cast<unsigned long long>(c_cull));
+        if (c_centre) atomicAdd(&ctl->rays_centre, static_cast<unsigned long long>(c_centre));
+        if (COUNT) {
+            if (c_box) atomicAdd(&ctl->box_tests, static_cast<unsigned long long>(c_box));
+            if (c_ref) atomicAdd(&ctl->leaf_tri_refs, static_cast<unsigned long long>(c_ref));
+        }
+    }
+}
+
+// ======================================================================================================
+// K2: area-light sample shadow rays (phongShade's lightStrikes(hitPoint, samples), flyscene.cpp:834-836).
+// One wave = the N samples of one (hit, light) pair (N = 64), several pairs per wave (N < 64) or
+// ceil(N/64) wave passes per pair (N > 64).  Output: one visibility bit per sample.
+// ======================================================================================================
+template <bool COUNT>
+__global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const DScene S, const DLights L, const int level, const int ctr_slot,
+                                                           const int lslots, const ShadeItem *__restrict__ items,
+                                                           Control *__restrict__ ctl, unsigned long long *__restrict__ vis) {
+    __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
+    __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK};
+    const uint32_t n_items = ctl->n_items[level];
+    const uint32_t N = static_cast<uint32_t>(L.n_samples);
+    const uint32_t groups = n_items * static_cast<uint32_t>(lslots);
+    const uint32_t G = N <= 64u ? 64u / N : 1u;              // (hit,light) pairs per wave
+    const uint32_t P = (N + 63u) / 64u;                       // 64-sample passes (= mask words) per pair
+    const unsigned long long units = N <= 64u ? (static_cast<unsigned long long>(groups) + G - 1u) / G
+                                              : static_cast<unsigned long long>(groups) * P;
+    const rt_node root = S.nodes[0];
+    const uint32_t slot = N <= 64u ? static_cast<uint32_t>(lane) / N : 0u;
+    const uint32_t s_in = N <= 64u ? static_cast<uint32_t>(lane) - slot * N : static_cast<uint32_t>(lane);
+
+    uint32_t c_rays = 0, c_box = 0, c_ref = 0;
+    for (;;) {
+        uint32_t unit = 0;
+        if (lane == 0) unit = atomicAdd(&ctl->tile_ctr[ctr_slot], 1u);
+        unit = uniform_u32(unit);
+        if (unit >= units) break;
+
+        uint32_t g, s, pass = 0;
+        bool valid;
+        if (N <= 64u) {
+            g = unit * G + slot; s = s_in;
+            valid = (slot < G) && (g < groups);
+        } else {
+            g = unit / P; pass = unit - g * P; s = pass * 64u + s_in;
+            valid = s < N;
+        }
+        const uint32_t item_i = valid ? g / static_cast<uint32_t>(lslots) : 0u;
+        const int l = valid ? static_cast<int>(g - item_i * static_cast<uint32_t>(lslots)) : 0;
+        const ShadeItem it = items[item_i];
+        const int nl = it.lmode ? 1 : L.n_lights;
+        valid = valid && (l < nl);
+        const float hx = it.ox + it.t * it.dx, hy = it.oy + it.t * it.dy, hz = it.oz + it.t * it.dz;
+        const float px = it.lmode ? it.lx : L.pos[l][0], py = it.lmode ? it.ly : L.pos[l][1], pz = it.lmode ? it.lz : L.pos[l][2];
+        float sx, sy, sz;
+        light_sample(L, px, py, pz, static_cast<int>(s), sx, sy, sz);
+        const float ddx = hx - sx, ddy = hy - sy, ddz = hz - sz;
+        c_rays += valid ? 1u : 0u;
+        if (COUNT && valid) c_box += 1;
+        const bool sroot = valid && box_hit(root.bmin, sx, sy, sz, ddx, ddy, ddz);
+        float t_unused = 0.f; int f_unused = -1;
+        bool occ = false;
+        packet_walk<true, COUNT>(S, stk, lane, sroot, sx, sy, sz, ddx, ddy, ddz, ddx, ddy, ddz, t_unused, f_unused, occ, c_box, c_ref);
+        const unsigned long long vm = __ballot(valid && !occ);
+        if (N <= 64u) {
+            if (s_in == 0u && slot < G && g < groups) {
+                const unsigned long long low = N == 64u ? ~0ull : ((1ull << N) - 1ull);
+                vis[g] = (vm >> (slot * N)) & low;
+            }
+        } else if (lane == 0) {
+            vis[static_cast<unsigned long long>(g) * P + pass] = vm;
+        }
+    }
+    c_rays = wave_sum(c_rays);
+    if (COUNT) { c_box = wave_sum(c_box); c_ref = wave_sum(c_ref); }
+    if (lane == 0) {
+        if (c_rays) atomicAdd(&ctl->rays_sample, static_cast<unsigned long long>(c_rays));
+        if (COUNT) {
+            if (c_box) atomicAdd(&ctl->box_tests_shadow, static_cast<unsigned long long>(c_box));
+            if (c_ref) atomicAdd(&ctl->leaf_tri_refs_shadow, static_cast<unsigned long long>(c_ref));
+        }
+    }
+}
+
+// ======================================================================================================
+// K3: Phong shading of lit hits + material dispatch + bounce-ray emission with wave-level compaction.
+// phongShade flyscene.cpp:822-859, getInterpolatedNormal :864-888, fresnel :890-910, traceRay dispatch :712-760.
+// ======================================================================================================
+__device__ __forceinline__ float fresnel_term(float ix, float iy, float iz, float nx, float ny, float nz, float ior) {
+    float cosi = dot3(ix, iy, iz, nx, ny, nz);
+    float etai = 1, etat = ior;
+    if (cosi > 0) { const float tmp = etai; etai = etat; etat = tmp; }
+    const float sint = etai / etat * sqrtf(smax(0.f, 1 - cosi * cosi));
+    if (sint >= 1) return 1;
+    const float cost = sqrtf(smax(0.f, 1 - sint * sint));
+    cosi = fabsf(cosi);
+    const float Rs = ((etat * cosi) - (etai * cost)) / ((etat * cosi) + (etai * cost));
+    const float Rp = ((etai * cosi) - (etat * cost)) / ((etai * cosi) + (etat * cost));
+    return (Rs * Rs + Rp * Rp) / 2;
+}
+
+__global__ __launch_bounds__(256) void k_shade(const DScene S, const DLights L, const DFrame F, const int level, const int ctr_slot,
+                                               const int lslots, const ShadeItem *__restrict__ items, Control *__restrict__ ctl,
+                                               const unsigned long long *__restrict__ vis, float4 *__restrict__ rec,
+                                               float *__restrict__ fres, RayItem *__restrict__ rays_out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_items = ctl->n_items[level];
+    const uint32_t ntiles = (n_items + 63u) / 64u;
+    const uint32_t N = static_cast<uint32_t>(L.n_samples);
+    const uint32_t P = (N + 63u) / 64u;
+    uint32_t c_shaded = 0, c_spawn = 0;
+    for (;;) {
+        uint32_t tile = 0;
+        if (lane == 0) tile = atomicAdd(&ctl->tile_ctr[ctr_slot], 1u);
+        tile = uniform_u32(tile);
+        if (tile >= ntiles) break;
+        const uint32_t idx = tile * 64u + static_cast<uint32_t>(lane);
+        const bool valid = idx < n_items;
+        const ShadeItem it = items[valid ? idx : 0u];
+        bool spawn = false;
+        RayItem child;
+        child.pad = 0u;
+        if (valid) {
+            c_shaded += 1;
+            const int face = it.face;
+            const float hx = it.ox + it.t * it.dx, hy = it.oy + it.t * it.dy, hz = it.oz + it.t * it.dz;
+            const float *tv = S.tri_verts + static_cast<size_t>(face) * 9;
+            const float Ax = tv[0], Ay = tv[1], Az = tv[2], Bx = tv[3], By = tv[4], Bz = tv[5], Cx = tv[6], Cy = tv[7], Cz = tv[8];
+            const uint32_t ia = S.tri_vid[face * 3], ib = S.tri_vid[face * 3 + 1], ic = S.tri_vid[face * 3 + 2];
+            const float *nA = S.vert_normal + static_cast<size_t>(ia) * 3, *nB = S.vert_normal + static_cast<size_t>(ib) * 3,
+                        *nC = S.vert_normal + static_cast<size_t>(ic) * 3;
+            const rt_material mat = S.mats[S.mat_id[face]];
+            const float fnx = S.face_normal[face * 3], fny = S.face_normal[face * 3 + 1], fnz = S.face_normal[face * 3 + 2];
+
+            // getInterpolatedNormal
+            const float v0x = Bx - Ax, v0y = By - Ay, v0z = Bz - Az;
+            const float v1x = Cx - Ax, v1y = Cy - Ay, v1z = Cz - Az;
+            const float v2x = hx - Ax, v2y = hy - Ay, v2z = hz - Az;
+            const float d00 = dot3(v0x, v0y, v0z, v0x, v0y, v0z), d01 = dot3(v0x, v0y, v0z, v1x, v1y, v1z);
+            const float d11 = dot3(v1x, v1y, v1z, v1x, v1y, v1z);
+            const float d20 = dot3(v2x, v2y, v2z, v0x, v0y, v0z), d21 = dot3(v2x, v2y, v2z, v1x, v1y, v1z);
+            const float denom = d00 * d11 - d01 * d01;
+            const float bv = (d11 * d20 - d01 * d21) / denom;
+            const float bw = (d00 * d21 - d01 * d20) / denom;
+            const float bu = 1.0f - bv - bw;
+            float inx = (bu * nA[0] + bv * nB[0]) + bw * nC[0];
+            float iny = (bu * nA[1] + bv * nB[1]) + bw * nC[1];
+            float inz = (bu * nA[2] + bv * nB[2]) + bw * nC[2];
+            // mesh.getModelMatrix() * n: Affine * Vector3f adds the translation (flyscene.cpp:829)
+            const float *M = S.model;
+            float nx = ((M[0] * inx + M[1] * iny) + M[2] * inz) + M[3] * 1.0f;
+            float ny = ((M[4] * inx + M[5] * iny) + M[6] * inz) + M[7] * 1.0f;
+            float nz = ((M[8] * inx + M[9] * iny) + M[10] * inz) + M[11] * 1.0f;
+            normalize3(nx, ny, nz);
+            // eyeToHitPoint = (-1 * (hitPoint - origin)).normalized(): invariant over samples
+            float ex = -1.0f * (hx - it.ox), ey = -1.0f * (hy - it.oy), ez = -1.0f * (hz - it.oz);
+            normalize3(ex, ey, ez);
+
+            float fr = 0.f, fg = 0.f, fb = 0.f;
+            const int nl = it.lmode ? 1 : L.n_lights;
+            for (int l = 0; l < nl; ++l) {
+                const float px = it.lmode ? it.lx : L.pos[l][0], py = it.lmode ? it.ly : L.pos[l][1], pz = it.lmode ? it.lz : L.pos[l][2];
+                const unsigned long long *vw = vis + (static_cast<unsigned long long>(idx) * static_cast<unsigned long long>(lslots) + static_cast<unsigned long long>(l)) * P;
+                float sum = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+                unsigned long long word = 0ull;
+                for (uint32_t s = 0; s < N; ++s) {
+                    if ((s & 63u) == 0u) word = vw[s >> 6];
+                    if (!((word >> (s & 63u)) & 1ull)) continue;
+                    sum += 1.0f;
+                    float sx, sy, sz;
+                    light_sample(L, px, py, pz, static_cast<int>(s), sx, sy, sz);
+                    float ldx = sx - hx, ldy = sy - hy, ldz = sz - hz;
+                    normalize3(ldx, ldy, ldz);
+                    const float ldn = dot3(ldx, ldy, ldz, nx, ny, nz);
+                    const float costheta = smax(0.0f, ldn);
+                    const float two = 2 * ldn;
+                    float rx = ldx - two * nx, ry = ldy - two * ny, rz = ldz - two * nz;
+                    normalize3(rx, ry, rz);
+                    const float cosphi = smax(0.0f, dot3(ex, ey, ez, -1.0f * rx, -1.0f * ry, -1.0f * rz));
+                    // powf(cosphi, Ns): evaluated in double and rounded once (within 1 ulp of glibc's powf)
+                    const float pw = static_cast<float>(pow(static_cast<double>(cosphi), static_cast<double>(mat.shininess)));
+                    cr = cr + ((L.color[0] * mat.kd[0]) * costheta + (L.color[0] * mat.ks[0]) * pw);
+                    cg = cg + ((L.color[1] * mat.kd[1]) * costheta + (L.color[1] * mat.ks[1]) * pw);
+                    cb = cb + ((L.color[2] * mat.kd[2]) * costheta + (L.color[2] * mat.ks[2]) * pw);
+                }
+                const float a = sum / static_cast<float>(N), b = 1.3f / static_cast<float>(N);
+                fr = fr + (cr * a) * b;
+                fg = fg + (cg * a) * b;
+                fb = fb + (cb * a) * b;
+            }
+
+            // material dispatch (flyscene.cpp:712-760); a hit at level == max_depth is plain Phong (extension)
+            const int imodel = mat.illum;
+            uint32_t kind = KIND_CONST;
+            if (level < F.max_depth) {
+                if (imodel == 9) {
+                    kind = KIND_PASS;
+                    child.dx = it.dx; child.dy = it.dy; child.dz = it.dz;
+                    child.lx = it.lx; child.ly = it.ly; child.lz = it.lz; child.lmode = it.lmode;
+                } else if (imodel == 6) {
+                    kind = KIND_REFRACT;
+                    const float c1 = fabsf(dot3(it.dx, it.dy, it.dz, fnx, fny, fnz));
+                    const float inv = 1 / mat.optical_density;
+                    const double p1 = static_cast<double>(inv) * static_cast<double>(inv);     // pow((1/Ni), 2)
+                    const double p2 = static_cast<double>(c1) * static_cast<double>(c1);       // pow(c1, 2)
+                    const float c2 = static_cast<float>(sqrt(1 - p1 * (1 - p2)));
+                    const float k = inv * c1 - c2;
+                    child.dx = inv * it.dx + k * fnx; child.dy = inv * it.dy + k * fny; child.dz = inv * it.dz + k * fnz;
+                    child.lx = it.lx; child.ly = it.ly; child.lz = it.lz; child.lmode = it.lmode;
+                } else if (imodel > 2 && imodel < 6) {
+                    kind = imodel == 5 ? KIND_FRESNEL : KIND_MIRROR;
+                    const float two = 2 * dot3(it.dx, it.dy, it.dz, fnx, fny, fnz);
+                    child.dx = it.dx - two * fnx; child.dy = it.dy - two * fny; child.dz = it.dz - two * fnz;
+                    child.lx = hx; child.ly = hy; child.lz = hz; child.lmode = 1u;             // reflectedLights = {hitPoint}
+                    if (imodel == 5) fres[it.pix] = fresnel_term(child.dx, child.dy, child.dz, fnx, fny, fnz, mat.optical_density);
+                }
+            }
+            rec[it.pix] = make_float4(fr, fg, fb, __uint_as_float(kind));
+            if (kind != KIND_CONST) {
+                spawn = true;
+                child.ox = hx; child.oy = hy; child.oz = hz; child.pix = it.pix;
+            }
+        }
+        const unsigned long long sm = __ballot(spawn);
+        if (sm != 0ull) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&ctl->n_rays[level + 1], static_cast<uint32_t>(__popcll(sm)));
+            base = uniform_u32(base);
+            if (spawn) { rays_out[base + lanes_below(sm)] = child; c_spawn += 1; }
+        }
+    }
+    c_shaded = wave_sum(c_shaded);
+    (void)c_spawn;
+    if (lane == 0 && c_shaded) atomicAdd(&ctl->shaded_hits, static_cast<unsigned long long>(c_shaded));
+}
+
+// ======================================================================================================
+// K4: resolve.  Folds the per-level records from the deepest level outwards -- c_k = a*phong_k + b*c_{k+1} --
+// which keeps the recursion's rounding (a running throughput product would not), then quantises like
+// writePPMImage (ppmIO.hpp:145): min(255, (int)(255*c)).
+// ======================================================================================================
+__global__ __launch_bounds__(256) void k_resolve(const DFrame F, const float4 *__restrict__ rec, const float *__restrict__ fres,
+                                                 float *__restrict__ out_rgb, uint8_t *__restrict__ out_u8) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x; pix < F.npix; pix += stride) {
+        int k = 0;
+        float4 r = rec[pix];
+        while (__float_as_uint(r.w) != KIND_CONST && k < F.max_depth) {
+            ++k;
+            r = rec[static_cast<size_t>(k) * F.npix + pix];
+        }
+        float vr = r.x, vg = r.y, vb = r.z;
+        for (int j = k - 1; j >= 0; --j) {
+            const float4 p = rec[static_cast<size_t>(j) * F.npix + pix];
+            const uint32_t kind = __float_as_uint(p.w);
+            float a, b;
+            if (kind == KIND_PASS) { a = 0.10f; b = 0.90f; }
+            else if (kind == KIND_REFRACT) { a = 0.2f; b = 0.8f; }
+            else { a = 0.15f; b = 0.85f; }
+            vr = a * p.x + b * vr; vg = a * p.y + b * vg; vb = a * p.z + b * vb;
+            if (kind == KIND_FRESNEL) {
+                const float f = fres[static_cast<size_t>(j) * F.npix + pix];
+                vr = f * vr; vg = f * vg; vb = f * vb;
+            }
+        }
+        if (out_rgb) { out_rgb[pix * 3] = vr; out_rgb[pix * 3 + 1] = vg; out_rgb[pix * 3 + 2] = vb; }
+        if (out_u8) {
+            const float c3[3] = {vr, vg, vb};
+            for (int c = 0; c < 3; ++c) {
+                int q = static_cast<int>(255 * c3[c]);
+                q = q < 255 ? q : 255;
+                out_u8[pix * 3 + c] = static_cast<uint8_t>(q < 0 ? 0 : q);
+            }
+        }
+    }
+}
+
+// ======================================================================================================
+// lightStrikes on explicit segments (rt_light_strikes): lane = segment light[i] -> hit[i]
+// ======================================================================================================
+__global__ __launch_bounds__(RT_WAVES * 64) void k_segments(const DScene S, const int n, const float *__restrict__ hit,
+                                                             const float *__restrict__ light, uint8_t *__restrict__ vis) {
+    __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
+    __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK};
+    const rt_node root = S.nodes[0];
+    const int waves_total = gridDim.x * RT_WAVES;
+    for (int base = (blockIdx.x * RT_WAVES + wave) * 64; base < n; base += waves_total * 64) {
+        const int i = base + lane;
+        const bool valid = i < n;
+        const int j = valid ? i : 0;
+        const float px = light[j * 3], py = light[j * 3 + 1], pz = light[j * 3 + 2];
+        const float ddx = hit[j * 3] - px, ddy = hit[j * 3 + 1] - py, ddz = hit[j * 3 + 2] - pz;
+        const bool sroot = valid && box_hit(root.bmin, px, py, pz, ddx, ddy, ddz);
+        float t_unused = 0.f; int f_unused = -1; bool occ = false; uint32_t c0 = 0, c1 = 0;
+        packet_walk<true, false>(S, stk, lane, sroot, px, py, pz, ddx, ddy, ddz, ddx, ddy, ddz, t_unused, f_unused, occ, c0, c1);
+        if (valid) vis[i] = occ ? 0 : 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host-callable launchers (keep <<<>>> syntax inside this translation unit)
+// ------------------------------------------------------------------------------------------------------
+void launch_trace(bool primary, bool count, int grid, hipStream_t st, const DScene &S, const DCam &cam, const DLights &L, const DFrame &F,
+                  int level, int slot, const RayItem *rays_in, ShadeItem *items, Control *ctl, float4 *rec, int32_t *out_hit, float *out_t) {
+    const dim3 g(grid), b(RT_WAVES * 64);
+    if (primary) {
+        if (count) hipLaunchKernelGGL((k_trace<true, true>), g, b, 0, st, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
+        else hipLaunchKernelGGL((k_trace<true, false>), g, b, 0, st, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
+    } else {
+        if (count) hipLaunchKernelGGL((k_trace<false, true>), g, b, 0, st, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
+        else hipLaunchKernelGGL((k_trace<false, false>), g, b, 0, st, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
+    }
+}
+
+void launch_shadow(bool count, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
+                   const ShadeItem *items, Control *ctl, unsigned long long *vis) {
+    const dim3 g(grid), b(RT_WAVES * 64);
+    if (count) hipLaunchKernelGGL((k_shadow<true>), g, b, 0, st, S, L, level, slot, lslots, items, ctl, vis);
+    else hipLaunchKernelGGL((k_shadow<false>), g, b, 0, st, S, L, level, slot, lslots, items, ctl, vis);
+}
+
+void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level, int slot, int lslots,
+                  const ShadeItem *items, Control *ctl, const unsigned long long *vis, float4 *rec, float *fres, RayItem *rays_out) {
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(256), 0, st, S, L, F, level, slot, lslots, items, ctl, vis, rec, fres, rays_out);
+}
+
+void launch_resolve(int grid, hipStream_t st, const DFrame &F, const float4 *rec, const float *fres, float *out_rgb, uint8_t *out_u8) {
+    hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, st, F, rec, fres, out_rgb, out_u8);
+}
+
+void launch_segments(int grid, hipStream_t st, const DScene &S, int n, const float *hit, const float *light, uint8_t *vis) {
+    hipLaunchKernelGGL(k_segments, dim3(grid), dim3(RT_WAVES * 64), 0, st, S, n, hit, light, vis);
+}
+
+}  // namespace rtamd
