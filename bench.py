@@ -189,7 +189,8 @@ def main():
         import oracle_lib
         orc = oracle_lib.load()
         osc = orc.load_scene(scene_path)
-        threads = max(1, (os.cpu_count() or 2) - 1)          # the reference uses hardware_concurrency()-1 (flyscene.cpp:558)
+        # the reference uses hardware_concurrency()-1 threads (flyscene.cpp:558); a 1-GPU box's CPU share is 16 cores
+        threads = max(1, min(16, os.cpu_count() or 2) - 1)
         stride = args.cpu_stride or 1
         n, sec, ost = osc.render_subsample(orc.camera(W, H), orc.lights(area=True, usteps=G, vsteps=G), W, H, stride, max_depth=D, threads=threads)
         cpu_rays = ost.total_rays()

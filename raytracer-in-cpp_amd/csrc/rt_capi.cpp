@@ -22,6 +22,7 @@ void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, c
                   const ShadeItem *items, Control *ctl, const unsigned long long *vis, float4 *rec, float *fres, RayItem *rays_out);
 void launch_resolve(int grid, hipStream_t st, const DFrame &F, const float4 *rec, const float *fres, float *out_rgb, uint8_t *out_u8);
 void launch_segments(int grid, hipStream_t st, const DScene &S, int n, const float *hit, const float *light, uint8_t *vis);
+void query_occupancy(int *trace_primary, int *trace_rays, int *shadow, int *shade);
 }  // namespace rtamd
 
 using namespace rtamd;
@@ -33,6 +34,7 @@ struct rt_host_scene {
 struct rt_ctx {
     int device = 0;
     int cus = 256;
+    int occ_trace_primary = 4, occ_trace_rays = 4, occ_shadow = 4, occ_shade = 2;   // resident blocks per CU
     hipStream_t stream = nullptr;
     std::string err;
     // scene
@@ -92,6 +94,7 @@ extern "C" rt_status rt_create(rt_ctx **out, int device) {
     if (hipSetDevice(device) != hipSuccess) { delete c; return RT_ERR_NO_DEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    query_occupancy(&c->occ_trace_primary, &c->occ_trace_rays, &c->occ_shadow, &c->occ_shade);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RT_ERR_HIP; }
     if (hipMalloc(reinterpret_cast<void **>(&c->d_ctl), sizeof(Control)) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return RT_ERR_HIP; }
     *out = c;
@@ -283,7 +286,6 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
     if (s != RT_OK) return s;
     HIPCHK(c, hipMemsetAsync(c->d_ctl, 0, sizeof(Control), st));
     if (!primary) HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->d_ctl->n_rays[0]), static_cast<int>(n_input_rays), 1, st));
-    const int grid = c->cus * 8;
     size_t ev = c->ev_base;
     DCam cam0{};
     if (cam) cam0 = *cam;
@@ -292,12 +294,12 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
         float4 *rec_l = c->d_rec + static_cast<size_t>(level) * F.npix;
         float *fres_l = c->d_fres + static_cast<size_t>(level) * F.npix;
         const bool prim = primary && level == 0;
-        launch_trace(prim, count, grid, st, c->S, cam0, L, F, level, 3 * level, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
+        launch_trace(prim, count, c->cus * (prim ? c->occ_trace_primary : c->occ_trace_rays), st, c->S, cam0, L, F, level, 3 * level, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
                      level == 0 ? d_hit : nullptr, level == 0 ? d_t : nullptr);
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
-        launch_shadow(count, grid, st, c->S, L, level, 3 * level + 1, lslots, c->d_items, c->d_ctl, c->d_vis);
+        launch_shadow(count, c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, c->d_items, c->d_ctl, c->d_vis);
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
-        launch_shade(c->cus * 4, st, c->S, L, F, level, 3 * level + 2, lslots, c->d_items, c->d_ctl, c->d_vis, rec_l, fres_l, c->d_rays[(level + 1) & 1]);
+        launch_shade(c->cus * c->occ_shade, st, c->S, L, F, level, 3 * level + 2, lslots, c->d_items, c->d_ctl, c->d_vis, rec_l, fres_l, c->d_rays[(level + 1) & 1]);
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
     }
     DFrame Fr = F;

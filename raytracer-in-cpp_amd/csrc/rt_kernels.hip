@@ -9,10 +9,11 @@
 //     child / a leaf.  This reproduces BoxTree::intersect's result exactly (src/boxTree.cpp:150-173: a lane's
 //     candidate set = faces of every non-empty leaf whose whole ancestor chain its ray's box tests accept) while
 //     touching each node/triangle once per wave instead of once per ray.
-//   * PERSISTENT WAVES.  Every kernel is launched with a fixed grid; waves pull tiles from a device-side queue
-//     head (one returning atomicAdd per tile).  Work sizes that depend on earlier kernels (lit hits, bounce
-//     rays) are read from device memory, so a whole frame is a fixed launch sequence with no host round trip
-//     and can be captured in a hipGraph.
+//   * PERSISTENT WAVES.  Every kernel is launched with a fixed grid sized to its residency (CUs x blocks/CU from
+//     the occupancy query); wave w takes tiles w, w + W, w + 2W, ... (static stride: a single atomic queue head
+//     was measured to cap the whole kernel at ~88 tiles/us).  Work sizes that depend on earlier kernels (lit
+//     hits, bounce rays) are read from device memory, so a whole frame is a fixed launch sequence with no host
+//     round trip and can be captured in a hipGraph.
 //   * Shadow samples are a SEPARATE kernel (k_shadow) so rocprof attributes traversal time to
 //     closest-hit (k_trace) vs area-light shadow rays (k_shadow) separately.
 //   * Ray compaction between bounces uses wave-wide ballot + mbcnt prefix and one atomicAdd per wave.
@@ -64,6 +65,10 @@ __device__ __forceinline__ bool box_hit(const float *__restrict__ b, float ox, f
     return !((tin > tout) || (tout < 0));
 }
 
+// The node and leaf-triangle arrays reach the kernels as separate `const T *__restrict__` parameters (noalias +
+// readonly): only then can the compiler prove that no store in the kernel clobbers them and select the
+// wave-uniform loads as s_load_dwordx8/x16 (scalar cache, SGPR destination) instead of 64-lane global_loads.
+
 struct WaveStack {
     uint32_t *node;
     unsigned long long *mask;
@@ -78,7 +83,8 @@ struct WaveStack {
 //   COUNT = true : no early-out; counts boxIntersect calls / leaf face references with the reference's semantics
 //                  (every pushed node is box-tested again when popped, boxTree.cpp:158,164).
 template <bool ANY, bool COUNT>
-__device__ __forceinline__ void packet_walk(const DScene &S, const WaveStack stk, const int lane, bool in_root,
+__device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
+                                            const WaveStack stk, const int lane, bool in_root,
                                             const float ox, const float oy, const float oz,      // ray origin
                                             const float dx, const float dy, const float dz,      // triangle-test direction
                                             const float bx, const float by, const float bz,      // box-test direction (dest - origin)
@@ -103,11 +109,11 @@ __device__ __forceinline__ void packet_walk(const DScene &S, const WaveStack stk
             mine = mine && !occluded;
             if (__ballot(mine) == 0ull) continue;
         }
-        const rt_node nd = S.nodes[ni];
+        const rt_node nd = nodes[ni];
         const uint32_t cnt = nd.count_flags & 0x7fffffffu;
         if (nd.count_flags & RT_NODE_LEAF) {
             if (COUNT && mine) cnt_ref += cnt;
-            const TriRec *__restrict__ T = S.leaf_tris + nd.first;
+            const TriRec *__restrict__ T = tris + nd.first;
             for (uint32_t k = 0; k < cnt; ++k) {
                 const TriRec tr = T[k];                       // wave-uniform address: scalar loads
                 if (mine && !(ANY && (tr.flags & 1u))) {
@@ -138,7 +144,7 @@ __device__ __forceinline__ void packet_walk(const DScene &S, const WaveStack stk
         } else {
             for (uint32_t c = 0; c < cnt; ++c) {
                 const uint32_t ci = nd.first + c;
-                const rt_node ch = S.nodes[ci];
+                const rt_node ch = nodes[ci];
                 const bool h = mine && box_hit(ch.bmin, ox, oy, oz, bx, by, bz);
                 if (COUNT && mine) cnt_box += h ? 2u : 1u;
                 const unsigned long long hm = __ballot(h);
@@ -175,7 +181,8 @@ __device__ __forceinline__ void light_sample(const DLights &L, const float px, c
 // and root-AABB cull of raytraceScene's serial loop (flyscene.cpp:573-598); otherwise reads compacted rays.
 // ======================================================================================================
 template <bool PRIMARY, bool COUNT>
-__global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const DScene S, const DCam cam, const DLights L, const DFrame F,
+__global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
+                                                          const DScene S, const DCam cam, const DLights L, const DFrame F,
                                                           const int level, const int ctr_slot,
                                                           const RayItem *__restrict__ rays_in, ShadeItem *__restrict__ items,
                                                           Control *__restrict__ ctl, float4 *__restrict__ rec,
@@ -186,14 +193,15 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const DScene S, const D
     const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK};
     const uint32_t n_in = PRIMARY ? 0u : ctl->n_rays[level];
     const uint32_t ntiles = PRIMARY ? static_cast<uint32_t>(F.tiles_x) * static_cast<uint32_t>(F.tiles_y) : (n_in + 63u) / 64u;
-    const rt_node root = S.nodes[0];
+    const rt_node root = nodes[0];
 
     uint32_t c_rays = 0, c_cull = 0, c_centre = 0, c_box = 0, c_ref = 0;
-    for (;;) {
-        uint32_t tile = 0;
-        if (lane == 0) tile = atomicAdd(&ctl->tile_ctr[ctr_slot], 1u);
-        tile = uniform_u32(tile);
-        if (tile >= ntiles) break;
+    // Static wave-strided tile assignment over a grid sized to the kernel's residency: a single device-side queue
+    // head saturates at ~88 dequeues/us on MI355X (one returning atomic per tile made the atomics, not the
+    // traversal, the bottleneck: 576k shadow units = 6.5 ms).  Neighbouring waves take neighbouring tiles.
+    const uint32_t wave_id = uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave));
+    const uint32_t wave_count = gridDim.x * RT_WAVES;
+    for (uint32_t tile = wave_id; tile < ntiles; tile += wave_count) {
 
         bool valid;
         uint32_t pix = 0, lmode = 0;
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const DScene S, const D
         float best_t = 3.402823466e+38f;
         int best_f = -1;
         bool dummy = false;
-        packet_walk<false, COUNT>(S, stk, lane, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz, best_t, best_f, dummy, c_box, c_ref);
+        packet_walk<false, COUNT>(nodes, tris, stk, lane, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz, best_t, best_f, dummy, c_box, c_ref);
         const bool hit = valid && (best_f >= 0);
         const float hx = ox + best_t * dx, hy = oy + best_t * dy, hz = oz + best_t * dz;   // flyscene.cpp:695
 
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const DScene S, const D
                 const bool sroot = act && box_hit(root.bmin, px, py, pz, sdx, sdy, sdz);
                 float t_unused = 0.f; int f_unused = -1;
                 bool occ = false;
-                packet_walk<true, COUNT>(S, stk, lane, sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz, t_unused, f_unused, occ, c_box, c_ref);
+                packet_walk<true, COUNT>(nodes, tris, stk, lane, sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz, t_unused, f_unused, occ, c_box, c_ref);
                 lit = lit || (act && !occ);
             }
         }
@@ -302,7 +310,8 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const DScene S, const D
 // ceil(N/64) wave passes per pair (N > 64).  Output: one visibility bit per sample.
 // ======================================================================================================
 template <bool COUNT>
-__global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const DScene S, const DLights L, const int level, const int ctr_slot,
+__global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
+                                                           const DScene S, const DLights L, const int level, const int ctr_slot,
                                                            const int lslots, const ShadeItem *__restrict__ items,
                                                            Control *__restrict__ ctl, unsigned long long *__restrict__ vis) {
     __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
@@ -316,16 +325,15 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const DScene S, const 
     const uint32_t P = (N + 63u) / 64u;                       // 64-sample passes (= mask words) per pair
     const unsigned long long units = N <= 64u ? (static_cast<unsigned long long>(groups) + G - 1u) / G
                                               : static_cast<unsigned long long>(groups) * P;
-    const rt_node root = S.nodes[0];
+    const rt_node root = nodes[0];
     const uint32_t slot = N <= 64u ? static_cast<uint32_t>(lane) / N : 0u;
     const uint32_t s_in = N <= 64u ? static_cast<uint32_t>(lane) - slot * N : static_cast<uint32_t>(lane);
 
     uint32_t c_rays = 0, c_box = 0, c_ref = 0;
-    for (;;) {
-        uint32_t unit = 0;
-        if (lane == 0) unit = atomicAdd(&ctl->tile_ctr[ctr_slot], 1u);
-        unit = uniform_u32(unit);
-        if (unit >= units) break;
+    const uint32_t wave_id = uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave));
+    const uint32_t wave_count = gridDim.x * RT_WAVES;
+    for (unsigned long long unit64 = wave_id; unit64 < units; unit64 += wave_count) {
+        const uint32_t unit = static_cast<uint32_t>(unit64);
 
         uint32_t g, s, pass = 0;
         bool valid;
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const DScene S, const 
         const bool sroot = valid && box_hit(root.bmin, sx, sy, sz, ddx, ddy, ddz);
         float t_unused = 0.f; int f_unused = -1;
         bool occ = false;
-        packet_walk<true, COUNT>(S, stk, lane, sroot, sx, sy, sz, ddx, ddy, ddz, ddx, ddy, ddz, t_unused, f_unused, occ, c_box, c_ref);
+        packet_walk<true, COUNT>(nodes, tris, stk, lane, sroot, sx, sy, sz, ddx, ddy, ddz, ddx, ddy, ddz, t_unused, f_unused, occ, c_box, c_ref);
         const unsigned long long vm = __ballot(valid && !occ);
         if (N <= 64u) {
             if (s_in == 0u && slot < G && g < groups) {
@@ -400,11 +408,9 @@ __global__ __launch_bounds__(256) void k_shade(const DScene S, const DLights L, 
     const uint32_t N = static_cast<uint32_t>(L.n_samples);
     const uint32_t P = (N + 63u) / 64u;
     uint32_t c_shaded = 0, c_spawn = 0;
-    for (;;) {
-        uint32_t tile = 0;
-        if (lane == 0) tile = atomicAdd(&ctl->tile_ctr[ctr_slot], 1u);
-        tile = uniform_u32(tile);
-        if (tile >= ntiles) break;
+    const uint32_t wave_id = uniform_u32(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t wave_count = gridDim.x * 4u;
+    for (uint32_t tile = wave_id; tile < ntiles; tile += wave_count) {
         const uint32_t idx = tile * 64u + static_cast<uint32_t>(lane);
         const bool valid = idx < n_items;
         const ShadeItem it = items[valid ? idx : 0u];
@@ -569,13 +575,14 @@ __global__ __launch_bounds__(256) void k_resolve(const DFrame F, const float4 *_
 // ======================================================================================================
 // lightStrikes on explicit segments (rt_light_strikes): lane = segment light[i] -> hit[i]
 // ======================================================================================================
-__global__ __launch_bounds__(RT_WAVES * 64) void k_segments(const DScene S, const int n, const float *__restrict__ hit,
+__global__ __launch_bounds__(RT_WAVES * 64) void k_segments(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
+                                                             const DScene S, const int n, const float *__restrict__ hit,
                                                              const float *__restrict__ light, uint8_t *__restrict__ vis) {
     __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
     __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK};
-    const rt_node root = S.nodes[0];
+    const rt_node root = nodes[0];
     const int waves_total = gridDim.x * RT_WAVES;
     for (int base = (blockIdx.x * RT_WAVES + wave) * 64; base < n; base += waves_total * 64) {
         const int i = base + lane;
@@ -585,9 +592,20 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_segments(const DScene S, cons
         const float ddx = hit[j * 3] - px, ddy = hit[j * 3 + 1] - py, ddz = hit[j * 3 + 2] - pz;
         const bool sroot = valid && box_hit(root.bmin, px, py, pz, ddx, ddy, ddz);
         float t_unused = 0.f; int f_unused = -1; bool occ = false; uint32_t c0 = 0, c1 = 0;
-        packet_walk<true, false>(S, stk, lane, sroot, px, py, pz, ddx, ddy, ddz, ddx, ddy, ddz, t_unused, f_unused, occ, c0, c1);
+        packet_walk<true, false>(nodes, tris, stk, lane, sroot, px, py, pz, ddx, ddy, ddz, ddx, ddy, ddz, t_unused, f_unused, occ, c0, c1);
         if (valid) vis[i] = occ ? 0 : 1;
     }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// residency: blocks per CU for each persistent kernel (fast variants), queried once per context
+// ------------------------------------------------------------------------------------------------------
+void query_occupancy(int *trace_primary, int *trace_rays, int *shadow, int *shade) {
+    int n = 0;
+    *trace_primary = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<true, false>, RT_WAVES * 64, 0) == hipSuccess && n > 0) ? n : 4;
+    *trace_rays = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<false, false>, RT_WAVES * 64, 0) == hipSuccess && n > 0) ? n : 4;
+    *shadow = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shadow<false>, RT_WAVES * 64, 0) == hipSuccess && n > 0) ? n : 4;
+    *shade = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, 256, 0) == hipSuccess && n > 0) ? n : 2;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -597,19 +615,19 @@ void launch_trace(bool primary, bool count, int grid, hipStream_t st, const DSce
                   int level, int slot, const RayItem *rays_in, ShadeItem *items, Control *ctl, float4 *rec, int32_t *out_hit, float *out_t) {
     const dim3 g(grid), b(RT_WAVES * 64);
     if (primary) {
-        if (count) hipLaunchKernelGGL((k_trace<true, true>), g, b, 0, st, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
-        else hipLaunchKernelGGL((k_trace<true, false>), g, b, 0, st, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
+        if (count) hipLaunchKernelGGL((k_trace<true, true>), g, b, 0, st, S.nodes, S.leaf_tris, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
+        else hipLaunchKernelGGL((k_trace<true, false>), g, b, 0, st, S.nodes, S.leaf_tris, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
     } else {
-        if (count) hipLaunchKernelGGL((k_trace<false, true>), g, b, 0, st, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
-        else hipLaunchKernelGGL((k_trace<false, false>), g, b, 0, st, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
+        if (count) hipLaunchKernelGGL((k_trace<false, true>), g, b, 0, st, S.nodes, S.leaf_tris, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
+        else hipLaunchKernelGGL((k_trace<false, false>), g, b, 0, st, S.nodes, S.leaf_tris, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
     }
 }
 
 void launch_shadow(bool count, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
                    const ShadeItem *items, Control *ctl, unsigned long long *vis) {
     const dim3 g(grid), b(RT_WAVES * 64);
-    if (count) hipLaunchKernelGGL((k_shadow<true>), g, b, 0, st, S, L, level, slot, lslots, items, ctl, vis);
-    else hipLaunchKernelGGL((k_shadow<false>), g, b, 0, st, S, L, level, slot, lslots, items, ctl, vis);
+    if (count) hipLaunchKernelGGL((k_shadow<true>), g, b, 0, st, S.nodes, S.leaf_tris, S, L, level, slot, lslots, items, ctl, vis);
+    else hipLaunchKernelGGL((k_shadow<false>), g, b, 0, st, S.nodes, S.leaf_tris, S, L, level, slot, lslots, items, ctl, vis);
 }
 
 void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level, int slot, int lslots,
@@ -622,7 +640,7 @@ void launch_resolve(int grid, hipStream_t st, const DFrame &F, const float4 *rec
 }
 
 void launch_segments(int grid, hipStream_t st, const DScene &S, int n, const float *hit, const float *light, uint8_t *vis) {
-    hipLaunchKernelGGL(k_segments, dim3(grid), dim3(RT_WAVES * 64), 0, st, S, n, hit, light, vis);
+    hipLaunchKernelGGL(k_segments, dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S, n, hit, light, vis);
 }
 
 }  // namespace rtamd
