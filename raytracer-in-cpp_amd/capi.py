@@ -14,7 +14,7 @@ RT_LIGHT_POINT, RT_LIGHT_AREA = 0, 1
 RT_NODE_LEAF = 0x80000000
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librt_mi355x.so")
+LIB_PATH = os.environ.get("RT_LIB") or os.path.join(_HERE, "lib", "librt_mi355x.so")
 
 
 class rt_node(C.Structure):

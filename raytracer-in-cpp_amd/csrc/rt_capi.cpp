@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -23,6 +24,7 @@ void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, c
 void launch_resolve(int grid, hipStream_t st, const DFrame &F, const float4 *rec, const float *fres, float *out_rgb, uint8_t *out_u8);
 void launch_segments(int grid, hipStream_t st, const DScene &S, int n, const float *hit, const float *light, uint8_t *vis);
 void query_occupancy(int *trace_primary, int *trace_rays, int *shadow, int *shade);
+void launch_set_prof(hipStream_t st, Control *ctl);
 }  // namespace rtamd
 
 using namespace rtamd;
@@ -95,6 +97,10 @@ extern "C" rt_status rt_create(rt_ctx **out, int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     query_occupancy(&c->occ_trace_primary, &c->occ_trace_rays, &c->occ_shadow, &c->occ_shade);
+    if (const char *gm = std::getenv("RT_GRID_MULT")) {          // tuning knob: grid = CUs x residency x mult
+        const int m = std::atoi(gm);
+        if (m > 0 && m <= 64) { c->occ_trace_primary *= m; c->occ_trace_rays *= m; c->occ_shadow *= m; c->occ_shade *= m; }
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RT_ERR_HIP; }
     if (hipMalloc(reinterpret_cast<void **>(&c->d_ctl), sizeof(Control)) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return RT_ERR_HIP; }
     *out = c;
@@ -285,6 +291,7 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
     rt_status s = ensure_frame(c, F.npix, D + 1, static_cast<size_t>(F.npix) * lslots * P);
     if (s != RT_OK) return s;
     HIPCHK(c, hipMemsetAsync(c->d_ctl, 0, sizeof(Control), st));
+    launch_set_prof(st, c->d_ctl);   // no-op unless built with -DRT_PROFILE
     if (!primary) HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->d_ctl->n_rays[0]), static_cast<int>(n_input_rays), 1, st));
     size_t ev = c->ev_base;
     DCam cam0{};
@@ -332,6 +339,15 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
     HIPCHK(c, hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
     out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample;
     out->pixels = F.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;
+#ifdef RT_PROFILE
+    if (!counted) {
+        std::fprintf(stderr, "RT_PROFILE ray-mode steps %llu useful %llu | tri-mode steps %llu useful %llu | box steps %llu useful %llu | leaves ray %llu tri %llu live-at-tri %llu\n",
+                     h.prof[0], h.prof[1], h.prof[2], h.prof[3], h.prof[4], h.prof[5], h.prof[6], h.prof[7], h.prof[8]);
+        std::fprintf(stderr, "RT_PROFILE shadow units %llu: cycles max %llu mean %.0f; log2 histogram:", h.prof[11], h.prof[9], h.prof[11] ? double(h.prof[10]) / double(h.prof[11]) : 0.0);
+        for (int b = 8; b <= 30; ++b) std::fprintf(stderr, " [2^%d]=%llu", b, h.prof[16 + b]);
+        std::fprintf(stderr, "\n");
+    }
+#endif
     if (counted) {
         out->box_tests = h.box_tests + h.box_tests_shadow; out->leaf_tri_refs = h.leaf_tri_refs + h.leaf_tri_refs_shadow;
         out->box_tests_shadow = h.box_tests_shadow; out->leaf_tri_refs_shadow = h.leaf_tri_refs_shadow;

@@ -102,14 +102,19 @@ struct DFrame {              // which pixels this launch covers
     int32_t max_depth;
 };
 
+#define RT_QUEUE_SHARDS 8
+
 // control block in device memory (zeroed once per frame by a memset node on the render stream)
 struct Control {
-    uint32_t tile_ctr[3 * (RT_MAX_DEPTH + 1) + 4];   // one work-queue head per launch
+    // work-queue heads: one set of RT_QUEUE_SHARDS counters per launch, each counter alone on a 64-byte line
+    uint32_t queue[3 * (RT_MAX_DEPTH + 1) + 4][RT_QUEUE_SHARDS * 16];
     uint32_t n_items[RT_MAX_DEPTH + 1];              // lit hits per level
     uint32_t n_rays[RT_MAX_DEPTH + 2];               // bounce rays per level (n_rays[0] = rt_trace_rays input count)
     unsigned long long rays_primary, rays_bounce, rays_centre, rays_sample, pixels_culled, shaded_hits;
     unsigned long long box_tests, leaf_tri_refs;              // k_trace (closest hit + light-centre rays)
     unsigned long long box_tests_shadow, leaf_tri_refs_shadow; // k_shadow (area-light sample rays)
+    // -DRT_PROFILE builds only: executed work (wave steps) and useful lane work per leaf mode / box tests
+    unsigned long long prof[64];
 };
 
 }  // namespace rtamd

@@ -10,8 +10,9 @@
 //     candidate set = faces of every non-empty leaf whose whole ancestor chain its ray's box tests accept) while
 //     touching each node/triangle once per wave instead of once per ray.
 //   * PERSISTENT WAVES.  Every kernel is launched with a fixed grid sized to its residency (CUs x blocks/CU from
-//     the occupancy query); wave w takes tiles w, w + W, w + 2W, ... (static stride: a single atomic queue head
-//     was measured to cap the whole kernel at ~88 tiles/us).  Work sizes that depend on earlier kernels (lit
+//     the occupancy query); waves pull CHUNKS of units from a sharded device-side queue (8 XCD-keyed heads on separate
+//     cache lines, interleaved chunk ownership, next index prefetched, stealing when drained).  Measured on the way here: a
+//     single atomic head caps a kernel at ~88 units/us; static striding leaves waves idle 58 % of the time.  Work sizes that depend on earlier kernels (lit
 //     hits, bounce rays) are read from device memory, so a whole frame is a fixed launch sequence with no host
 //     round trip and can be captured in a hipGraph.
 //   * Shadow samples are a SEPARATE kernel (k_shadow) so rocprof attributes traversal time to
@@ -69,10 +70,74 @@ __device__ __forceinline__ bool box_hit(const float *__restrict__ b, float ox, f
 // readonly): only then can the compiler prove that no store in the kernel clobbers them and select the
 // wave-uniform loads as s_load_dwordx8/x16 (scalar cache, SGPR destination) instead of 64-lane global_loads.
 
+// Dynamic work distribution without a single hot atomic (one queue head saturates at ~88 dequeues/us on MI355X;
+// plain static striding left waves resident only ~42 % of the kernel on the dodge scene).
+//   * units are handed out in CHUNKS of `chunk` consecutive units (chunk ~ units / (6 x waves), computed in-kernel
+//     because the unit count itself is produced on the device), so a wave performs only ~6 atomics per launch;
+//   * chunk c belongs to queue head c % 8; a workgroup uses head blockIdx % 8 -- blocks b and b+8 share an XCD, so
+//     each head is hit from one XCD's L2 -- and the interleaving keeps all 8 heads equally loaded, so stealing
+//     (next head, checked with a plain load first) only happens in the last few chunks;
+//   * the next chunk index is fetched BEFORE the current chunk is processed: the atomic's latency hides behind work.
+struct ShardedQueue {
+    uint32_t *ctr;
+    uint32_t total, chunk, nchunks, shard, tries, fetched, cur, cur_end;
+    int lane;
+    __device__ __forceinline__ uint32_t chunks_of(uint32_t s) const {         // chunks owned by head s
+        return nchunks / RT_QUEUE_SHARDS + ((nchunks % RT_QUEUE_SHARDS) > s ? 1u : 0u);
+    }
+    __device__ __forceinline__ uint32_t grab() {
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(&ctr[shard * 16u], 1u);
+        return v;
+    }
+    // static variant (no atomics at all): wave w owns units w, w + W, w + 2W, ...  Best when units are cheap and
+    // uniform (primary tiles: measured 0.25 ms static vs 0.39 ms dynamic on the cube frame).
+    __device__ __forceinline__ void init_static(uint32_t total_units, uint32_t total_waves, uint32_t wave_id, int ln) {
+        ctr = nullptr; total = 0u; lane = ln; chunk = 1u; nchunks = total_waves; shard = 0; tries = 0; fetched = 0;
+        cur = wave_id; cur_end = total_units;
+    }
+    __device__ __forceinline__ void init(uint32_t *heads, uint32_t total_units, uint32_t total_waves, uint32_t home, int ln) {
+        ctr = heads; total = total_units; lane = ln;
+        chunk = total_units / (total_waves * 6u);
+        if (chunk < 1u) chunk = 1u;
+        nchunks = (total_units + chunk - 1u) / chunk;          // chunk c = { c + j * nchunks }
+        shard = home % RT_QUEUE_SHARDS; tries = 0; cur = 0; cur_end = 0;
+        fetched = total ? grab() : 0u;
+    }
+    __device__ __forceinline__ bool next(uint32_t &unit) {
+        // a chunk is NOT a run of consecutive units: chunk c owns units c, c + nchunks, c + 2*nchunks, ...  Expensive
+        // units cluster (neighbouring hit points cross the same 979-triangle leaves); consecutive membership made
+        // single chunks 5x heavier than average and doubled the kernel's tail.
+        if (cur < cur_end) { unit = cur; cur += nchunks; return true; }
+        if (total == 0u) return false;
+        for (;;) {
+            const uint32_t idx = uniform_u32(fetched);
+            if (idx < chunks_of(shard)) {
+                cur = idx * RT_QUEUE_SHARDS + shard;
+                cur_end = total;
+                fetched = grab();                     // prefetch the following chunk index
+                unit = cur;
+                cur += nchunks;
+                return true;
+            }
+            for (;;) {
+                if (++tries >= RT_QUEUE_SHARDS) return false;
+                shard = (shard + 1u) % RT_QUEUE_SHARDS;
+                const uint32_t seen = uniform_u32(__hip_atomic_load(&ctr[shard * 16u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (seen < chunks_of(shard)) break;
+            }
+            fetched = grab();
+        }
+    }
+};
+
 struct WaveStack {
     uint32_t *node;
     unsigned long long *mask;
+    uint4 *stage;            // per-wave LDS staging buffer: RT_STAGE_TRIS leaf-triangle records (80 B each)
 };
+#define RT_STAGE_TRIS 64
+#define RT_SCALAR_LEAF_MAX 16   // leaves up to this size are walked with scalar loads straight from the scalar cache
 
 // Wave-uniform octree walk for 64 rays.
 //   ANY   = false: closest hit (flyscene.cpp:675-683): min t over candidates with t > 1e-5, ties to the lowest
@@ -82,6 +147,26 @@ struct WaveStack {
 //                  (not illum 9) has 1e-5 < t < 0.98 -- so a lane may stop at its first occluder (exact).
 //   COUNT = true : no early-out; counts boxIntersect calls / leaf face references with the reference's semantics
 //                  (every pushed node is box-tested again when popped, boxTree.cpp:158,164).
+__device__ __forceinline__ float lane_f(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
+// Per-leaf choice between the two lane mappings (wave-uniform): issue-cost estimates in VALU instructions.
+#ifdef RT_PROFILE
+// profiling build: wave-level step counters, flushed with one atomic per leaf/inner visit (slow, diagnostic only)
+__device__ unsigned long long *g_prof = nullptr;
+#define RT_PROF_ADD(lane, idx, val) do { const unsigned long long pv_ = static_cast<unsigned long long>(val); if ((lane) == 0 && g_prof) atomicAdd(&g_prof[(idx)], pv_); } while (0)
+#else
+#define RT_PROF_ADD(lane, idx, val) do { } while (0)
+#endif
+// prof[0] ray-mode triangle steps   prof[1] ray-mode useful lane tests
+// prof[2] tri-mode (ray,chunk) steps prof[3] tri-mode useful lane tests
+// prof[4] box-test steps            prof[5] box-test useful lanes
+// prof[6] leaves in ray mode        prof[7] leaves in tri mode   prof[8] sum of live rays at tri-mode leaves
+
+#define RT_COST_RAY_MODE 45u      // per triangle, lanes = rays (all 64 lanes step through every triangle)
+#define RT_COST_TRI_MODE 58u      // per (active ray, 64-triangle chunk), lanes = triangles
+
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
                                             const WaveStack stk, const int lane, bool in_root,
@@ -105,40 +190,125 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
         const uint32_t ni = uniform_u32(stk.node[sp]);
         const unsigned long long m = uniform_u64(stk.mask[sp]);
         bool mine = ((m >> lane) & 1ull) != 0ull;
-        if (ANY && !COUNT) {
-            mine = mine && !occluded;
-            if (__ballot(mine) == 0ull) continue;
-        }
+        if (ANY && !COUNT) mine = mine && !occluded;
+        unsigned long long live = __ballot(mine);          // rays that still need this node
+        if (live == 0ull) continue;
         const rt_node nd = nodes[ni];
         const uint32_t cnt = nd.count_flags & 0x7fffffffu;
         if (nd.count_flags & RT_NODE_LEAF) {
             if (COUNT && mine) cnt_ref += cnt;
             const TriRec *__restrict__ T = tris + nd.first;
-            for (uint32_t k = 0; k < cnt; ++k) {
-                const TriRec tr = T[k];                       // wave-uniform address: scalar loads
-                if (mine && !(ANY && (tr.flags & 1u))) {
-                    // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819
-                    const float dn = dot3(dx, dy, dz, tr.nx, tr.ny, tr.nz);
-                    if (dn != 0) {
-                        const float t = (tr.nA - dot3(ox, oy, oz, tr.nx, tr.ny, tr.nz)) / dn;
-                        const float v2x = (ox + t * dx) - tr.ax, v2y = (oy + t * dy) - tr.ay, v2z = (oz + t * dz) - tr.az;
+            const uint32_t chunks = (cnt + 63u) >> 6;
+            const bool tri_mode = static_cast<uint32_t>(__popcll(live)) * chunks * RT_COST_TRI_MODE < cnt * RT_COST_RAY_MODE;
+            RT_PROF_ADD(lane, tri_mode ? 7 : 6, 1);
+            if (tri_mode) {
+                RT_PROF_ADD(lane, 8, __popcll(live));
+                // ---- lanes = triangles.  Each lane keeps ONE leaf triangle in registers (coalesced 80-B records, next
+                // chunk prefetched); the active rays are broadcast one at a time with v_readlane and every lane tests
+                // its triangle against that ray.  A ballot reports the hits: exact early-out per ray for shadow rays,
+                // and a scalar pick of the (t, face) minimum for closest hit.  No per-triangle memory round trip.
+                unsigned long long occ_new = 0ull;
+                TriRec tr = T[static_cast<uint32_t>(lane) < cnt ? static_cast<uint32_t>(lane) : 0u];
+                for (uint32_t c0 = 0; c0 < cnt; c0 += 64u) {
+                    const uint32_t n = cnt - c0 < 64u ? cnt - c0 : 64u;
+                    const bool has = static_cast<uint32_t>(lane) < n && !(ANY && (tr.flags & 1u));
+                    const uint32_t nx = c0 + 64u + static_cast<uint32_t>(lane);
+                    const TriRec nxt = T[nx < cnt ? nx : 0u];                      // prefetch (uniformly skipped work is cheap)
+                    unsigned long long todo = live;
+                    while (todo != 0ull) {
+                        const int r = static_cast<int>(__builtin_ctzll(todo));
+                        todo &= todo - 1ull;
+                        const float rox = lane_f(ox, r), roy = lane_f(oy, r), roz = lane_f(oz, r);
+                        const float rdx = lane_f(dx, r), rdy = lane_f(dy, r), rdz = lane_f(dz, r);
+                        // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 (same operations as the ray-lane form)
+                        const float dn = dot3(rdx, rdy, rdz, tr.nx, tr.ny, tr.nz);
+                        const float t = (tr.nA - dot3(rox, roy, roz, tr.nx, tr.ny, tr.nz)) / dn;
+                        const float v2x = (rox + t * rdx) - tr.ax, v2y = (roy + t * rdy) - tr.ay, v2z = (roz + t * rdz) - tr.az;
                         const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
                         const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
                         const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
                         const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
-                        if ((u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f)) {
-                            if (ANY) {
-                                if (t < 0.98f) occluded = true;
-                            } else if (t < best_t || (t == best_t && static_cast<int>(tr.face) < best_f)) {
-                                best_t = t;
-                                best_f = static_cast<int>(tr.face);
+                        const bool inside = has && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f);
+                        RT_PROF_ADD(lane, 2, 1); RT_PROF_ADD(lane, 3, __popcll(__ballot(has)));
+                        if (ANY) {
+                            if (__ballot(inside && t < 0.98f) != 0ull) {
+                                occ_new |= 1ull << r;
+                                if (!COUNT) live &= ~(1ull << r);
+                            }
+                        } else {
+                            unsigned long long hm = __ballot(inside);
+                            if (hm != 0ull) {
+                                float bt = lane_f(best_t, r);
+                                int bf = __builtin_amdgcn_readlane(best_f, r);
+                                do {
+                                    const int l = static_cast<int>(__builtin_ctzll(hm));
+                                    hm &= hm - 1ull;
+                                    const float tl = lane_f(t, l);
+                                    const int fl = __builtin_amdgcn_readlane(static_cast<int>(tr.face), l);
+                                    if (tl < bt || (tl == bt && fl < bf)) { bt = tl; bf = fl; }
+                                } while (hm != 0ull);
+                                if (lane == r) { best_t = bt; best_f = bf; }
                             }
                         }
                     }
+                    if (ANY && !COUNT && live == 0ull) break;
+                    tr = nxt;
                 }
-                if (ANY && !COUNT && (k & 7u) == 7u) {
-                    mine = mine && !occluded;
-                    if (__ballot(mine) == 0ull) break;
+                if (ANY) occluded = occluded || (((occ_new >> lane) & 1ull) != 0ull);
+            } else {
+                // ---- lanes = rays: every lane steps through the leaf's triangles for its own ray.
+                // Small leaves: the records are wave-uniform scalar loads (s_load_dwordx16 + x4, scalar cache).
+                // Larger leaves: 64-triangle chunks are staged into this wave's LDS buffer with coalesced 16-byte
+                // loads (ONE memory round trip per chunk instead of one per triangle), then read back as LDS
+                // broadcasts (all lanes the same address), software-pipelined one record ahead.
+                auto test_lane = [&](const TriRec &tr) {
+                    if (mine && !(ANY && (tr.flags & 1u))) {
+                        // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819
+                        const float dn = dot3(dx, dy, dz, tr.nx, tr.ny, tr.nz);
+                        if (dn != 0) {
+                            const float t = (tr.nA - dot3(ox, oy, oz, tr.nx, tr.ny, tr.nz)) / dn;
+                            const float v2x = (ox + t * dx) - tr.ax, v2y = (oy + t * dy) - tr.ay, v2z = (oz + t * dz) - tr.az;
+                            const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
+                            const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
+                            const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
+                            const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
+                            if ((u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f)) {
+                                if (ANY) {
+                                    if (t < 0.98f) occluded = true;
+                                } else if (t < best_t || (t == best_t && static_cast<int>(tr.face) < best_f)) {
+                                    best_t = t;
+                                    best_f = static_cast<int>(tr.face);
+                                }
+                            }
+                        }
+                    }
+                };
+                if (cnt <= RT_SCALAR_LEAF_MAX) {
+                    for (uint32_t k = 0; k < cnt; ++k) {
+                        const TriRec tr = T[k];
+                        RT_PROF_ADD(lane, 0, 1); RT_PROF_ADD(lane, 1, __popcll(__ballot(mine)));
+                        test_lane(tr);
+                    }
+                } else {
+                    for (uint32_t c0 = 0; c0 < cnt; c0 += RT_STAGE_TRIS) {
+                        const uint32_t n = cnt - c0 < RT_STAGE_TRIS ? cnt - c0 : RT_STAGE_TRIS;
+                        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(T + c0);
+                        __builtin_amdgcn_wave_barrier();
+                        for (uint32_t q = static_cast<uint32_t>(lane); q < n * 5u; q += 64u) stk.stage[q] = src[q];
+                        __builtin_amdgcn_wave_barrier();
+                        const TriRec *staged = reinterpret_cast<const TriRec *>(stk.stage);
+                        TriRec cur = staged[0];
+                        for (uint32_t k = 0; k < n; ++k) {
+                            const TriRec nxt = staged[k + 1u < n ? k + 1u : k];
+                            RT_PROF_ADD(lane, 0, 1); RT_PROF_ADD(lane, 1, __popcll(__ballot(mine)));
+                            test_lane(cur);
+                            cur = nxt;
+                        }
+                        if (ANY && !COUNT) {
+                            mine = mine && !occluded;
+                            if (__ballot(mine) == 0ull) break;
+                        }
+                    }
                 }
             }
         } else {
@@ -146,6 +316,7 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                 const uint32_t ci = nd.first + c;
                 const rt_node ch = nodes[ci];
                 const bool h = mine && box_hit(ch.bmin, ox, oy, oz, bx, by, bz);
+                RT_PROF_ADD(lane, 4, 1); RT_PROF_ADD(lane, 5, __popcll(__ballot(mine)));
                 if (COUNT && mine) cnt_box += h ? 2u : 1u;
                 const unsigned long long hm = __ballot(h);
                 if (hm != 0ull) {
@@ -187,21 +358,19 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
                                                           const RayItem *__restrict__ rays_in, ShadeItem *__restrict__ items,
                                                           Control *__restrict__ ctl, float4 *__restrict__ rec,
                                                           int32_t *__restrict__ out_hit, float *__restrict__ out_t) {
-    __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
+    __shared__ uint4 s_stage[RT_WAVES * RT_STAGE_TRIS * 5];
     __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
+    __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK};
+    const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, s_stage + wave * RT_STAGE_TRIS * 5};
     const uint32_t n_in = PRIMARY ? 0u : ctl->n_rays[level];
     const uint32_t ntiles = PRIMARY ? static_cast<uint32_t>(F.tiles_x) * static_cast<uint32_t>(F.tiles_y) : (n_in + 63u) / 64u;
     const rt_node root = nodes[0];
 
     uint32_t c_rays = 0, c_cull = 0, c_centre = 0, c_box = 0, c_ref = 0;
-    // Static wave-strided tile assignment over a grid sized to the kernel's residency: a single device-side queue
-    // head saturates at ~88 dequeues/us on MI355X (one returning atomic per tile made the atomics, not the
-    // traversal, the bottleneck: 576k shadow units = 6.5 ms).  Neighbouring waves take neighbouring tiles.
-    const uint32_t wave_id = uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave));
-    const uint32_t wave_count = gridDim.x * RT_WAVES;
-    for (uint32_t tile = wave_id; tile < ntiles; tile += wave_count) {
+    ShardedQueue q;
+    q.init_static(ntiles, gridDim.x * RT_WAVES, uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave)), lane);
+    for (uint32_t tile = 0; q.next(tile);) {
 
         bool valid;
         uint32_t pix = 0, lmode = 0;
@@ -314,10 +483,11 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restr
                                                            const DScene S, const DLights L, const int level, const int ctr_slot,
                                                            const int lslots, const ShadeItem *__restrict__ items,
                                                            Control *__restrict__ ctl, unsigned long long *__restrict__ vis) {
-    __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
+    __shared__ uint4 s_stage[RT_WAVES * RT_STAGE_TRIS * 5];
     __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
+    __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK};
+    const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, s_stage + wave * RT_STAGE_TRIS * 5};
     const uint32_t n_items = ctl->n_items[level];
     const uint32_t N = static_cast<uint32_t>(L.n_samples);
     const uint32_t groups = n_items * static_cast<uint32_t>(lslots);
@@ -330,11 +500,12 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restr
     const uint32_t s_in = N <= 64u ? static_cast<uint32_t>(lane) - slot * N : static_cast<uint32_t>(lane);
 
     uint32_t c_rays = 0, c_box = 0, c_ref = 0;
-    const uint32_t wave_id = uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave));
-    const uint32_t wave_count = gridDim.x * RT_WAVES;
-    for (unsigned long long unit64 = wave_id; unit64 < units; unit64 += wave_count) {
-        const uint32_t unit = static_cast<uint32_t>(unit64);
-
+    ShardedQueue q;
+    q.init(ctl->queue[ctr_slot], static_cast<uint32_t>(units), gridDim.x * RT_WAVES, blockIdx.x, lane);
+    for (uint32_t unit = 0; q.next(unit);) {
+#ifdef RT_PROFILE
+        const long long prof_t0 = clock64();
+#endif
         uint32_t g, s, pass = 0;
         bool valid;
         if (N <= 64u) {
@@ -369,6 +540,16 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restr
         } else if (lane == 0) {
             vis[static_cast<unsigned long long>(g) * P + pass] = vm;
         }
+#ifdef RT_PROFILE
+        {   // per-unit cycle histogram: prof[16 + log2(cycles)], max in prof[9], sum in prof[10], count in prof[11]
+            const unsigned long long dt = static_cast<unsigned long long>(clock64() - prof_t0);
+            if (lane == 0 && g_prof) {
+                atomicMax(&g_prof[9], dt); atomicAdd(&g_prof[10], dt); atomicAdd(&g_prof[11], 1ull);
+                int b = 63 - __builtin_clzll(dt | 1ull); if (b > 40) b = 40;
+                atomicAdd(&g_prof[16 + b], 1ull);
+            }
+        }
+#endif
     }
     c_rays = wave_sum(c_rays);
     if (COUNT) { c_box = wave_sum(c_box); c_ref = wave_sum(c_ref); }
@@ -578,10 +759,11 @@ __global__ __launch_bounds__(256) void k_resolve(const DFrame F, const float4 *_
 __global__ __launch_bounds__(RT_WAVES * 64) void k_segments(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
                                                              const DScene S, const int n, const float *__restrict__ hit,
                                                              const float *__restrict__ light, uint8_t *__restrict__ vis) {
-    __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
+    __shared__ uint4 s_stage[RT_WAVES * RT_STAGE_TRIS * 5];
     __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
+    __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK};
+    const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, s_stage + wave * RT_STAGE_TRIS * 5};
     const rt_node root = nodes[0];
     const int waves_total = gridDim.x * RT_WAVES;
     for (int base = (blockIdx.x * RT_WAVES + wave) * 64; base < n; base += waves_total * 64) {
@@ -596,6 +778,13 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_segments(const rt_node *__res
         if (valid) vis[i] = occ ? 0 : 1;
     }
 }
+
+#ifdef RT_PROFILE
+__global__ void k_set_prof(Control *ctl) { g_prof = ctl->prof; }
+void launch_set_prof(hipStream_t st, Control *ctl) { hipLaunchKernelGGL(k_set_prof, dim3(1), dim3(1), 0, st, ctl); }
+#else
+void launch_set_prof(hipStream_t, Control *) {}
+#endif
 
 // ------------------------------------------------------------------------------------------------------
 // residency: blocks per CU for each persistent kernel (fast variants), queried once per context

@@ -1,0 +1,19 @@
+#!/bin/bash
+# PMC passes (separate from kernel-trace, per the pool's rules): usage tools_pmc.sh <scene> <tag>
+sc=${1:-dodge}; tag=${2:-pmc}
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/$tag
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $R/gpurun_out/$tag/a -o a --output-format csv -- python3 $R/bench.py --scene $sc --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/$tag/a.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD -d $R/gpurun_out/$tag/b -o b --output-format csv -- python3 $R/bench.py --scene $sc --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/$tag/b.log 2>&1
+python3 - <<PY
+import csv, collections, glob
+for part in ("a","b"):
+    for f in glob.glob("$R/gpurun_out/$tag/%s/*counter_collection.csv" % part):
+        agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+        for row in csv.DictReader(open(f)):
+            k = row["Kernel_Name"].split("(")[0][:40]
+            agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        for k, d in agg.items():
+            if "rtamd" in k: print(part, k, {c: round(v) for c, v in d.items()})
+PY
