@@ -282,7 +282,7 @@ static hipEvent_t event_at(rt_ctx *c, size_t i) {
 
 // One frame = memset(control) ; per level { trace ; shadow ; shade } ; resolve -- no host synchronisation inside.
 static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLights &L, DFrame F, bool primary, bool count,
-                           float *d_rgb, uint8_t *d_u8, int32_t *d_hit, float *d_t, bool timed, uint32_t n_input_rays) {
+                           float *d_rgb, uint8_t *d_u8, int32_t *d_hit, float *d_t, int timed, uint32_t n_input_rays) {
     const int D = F.max_depth;
     // bounce levels can only be populated when some material reflects/refracts
     const int levels_run = c->reflective ? D + 1 : 1;
@@ -296,6 +296,8 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
     size_t ev = c->ev_base;
     DCam cam0{};
     if (cam) cam0 = *cam;
+    // timed == 1: an event between every pair of launches (per-kernel breakdown; adds ~4 us per boundary)
+    // timed == 2: lean set for timed loops -- frame start, around each k_shadow launch, frame end
     if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
     for (int level = 0; level < levels_run; ++level) {
         float4 *rec_l = c->d_rec + static_cast<size_t>(level) * F.npix;
@@ -307,7 +309,7 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
         launch_shadow(count, c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, c->d_items, c->d_ctl, c->d_vis);
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
         launch_shade(c->cus * c->occ_shade, st, c->S, L, F, level, 3 * level + 2, lslots, c->d_items, c->d_ctl, c->d_vis, rec_l, fres_l, c->d_rays[(level + 1) & 1]);
-        if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
+        if (timed == 1) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
     }
     DFrame Fr = F;
     Fr.max_depth = levels_run - 1;
@@ -317,15 +319,21 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
     return RT_OK;
 }
 
-static rt_status sum_frame_times(rt_ctx *c, size_t ev, int levels_run, rt_stats *out) {
+static rt_status sum_frame_times(rt_ctx *c, size_t ev, int levels_run, rt_stats *out, bool lean) {
     float ms = 0.f;
     const size_t first = ev;
     for (int level = 0; level < levels_run; ++level) {
-        HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_trace += ms; ++ev;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_shadow += ms; ++ev;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_shade += ms; ++ev;
+        if (lean) {
+            // events: [.. trace ..] E [shadow] E [.. shade, next trace ..]: only the shadow interval is a single kernel
+            ++ev;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_shadow += ms; ++ev;
+        } else {
+            HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_trace += ms; ++ev;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_shadow += ms; ++ev;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_shade += ms; ++ev;
+        }
     }
-    HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_resolve += ms;
+    if (!lean) { HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_resolve += ms; }
     HIPCHK(c, hipEventElapsedTime(&ms, c->events[first], c->events[ev + 1])); out->ms_total += ms;
     out->launches_trace += static_cast<uint32_t>(levels_run);
     out->launches_shadow += static_cast<uint32_t>(levels_run);
@@ -355,7 +363,7 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
     if (timed) {
         out->ms_trace = out->ms_shadow = out->ms_shade = out->ms_resolve = out->ms_total = 0.f;
         out->launches_trace = out->launches_shadow = out->launches_shade = 0;
-        rt_status s = sum_frame_times(c, c->ev_base, levels_run, out);
+        rt_status s = sum_frame_times(c, c->ev_base, levels_run, out, false);
         if (s != RT_OK) return s;
     }
     return RT_OK;
@@ -407,19 +415,19 @@ extern "C" rt_status rt_render_device(rt_ctx *c, const rt_camera *cam, const rt_
     const int levels_run = c->reflective ? F.max_depth + 1 : 1;
     if (stats && p->collect_stats == 1) {
         // counting pass: same frame with the no-early-out traversal variants (never part of a timed region)
-        if ((s = run_frame(c, st, &dc, L, F, true, true, d_out_rgb, d_out_u8, d_out_hit, nullptr, false, 0)) != RT_OK) return s;
+        if ((s = run_frame(c, st, &dc, L, F, true, true, d_out_rgb, d_out_u8, d_out_hit, nullptr, 0, 0)) != RT_OK) return s;
         if ((s = fill_stats(c, st, F, levels_run, false, stats, true)) != RT_OK) return s;
     }
     if (p->collect_stats == 2) {
         const size_t first = c->ev_base;
-        if ((s = run_frame(c, st, &dc, L, F, true, false, d_out_rgb, d_out_u8, d_out_hit, nullptr, true, 0)) != RT_OK) return s;
+        if ((s = run_frame(c, st, &dc, L, F, true, false, d_out_rgb, d_out_u8, d_out_hit, nullptr, 2, 0)) != RT_OK) return s;
         c->pending.emplace_back(first, levels_run);
-        c->ev_base = first + static_cast<size_t>(3 * levels_run + 2);
+        c->ev_base = first + static_cast<size_t>(2 * levels_run + 2);
         c->pending_stream = st;
         c->pending_frame = F;
         return RT_OK;
     }
-    if ((s = run_frame(c, st, &dc, L, F, true, false, d_out_rgb, d_out_u8, d_out_hit, nullptr, stats != nullptr, 0)) != RT_OK) return s;
+    if ((s = run_frame(c, st, &dc, L, F, true, false, d_out_rgb, d_out_u8, d_out_hit, nullptr, stats != nullptr ? 1 : 0, 0)) != RT_OK) return s;
     if (stats) {
         const uint64_t bt = stats->box_tests, lr = stats->leaf_tri_refs, bts = stats->box_tests_shadow, lrs = stats->leaf_tri_refs_shadow;
         if ((s = fill_stats(c, st, F, levels_run, true, stats, false)) != RT_OK) return s;
@@ -440,7 +448,7 @@ extern "C" rt_status rt_timing_collect(rt_ctx *c, rt_stats *out) {
     out->pixels = c->pending_frame.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;
     rt_status s = RT_OK;
     for (const auto &fr : c->pending)
-        if ((s = sum_frame_times(c, fr.first, fr.second, out)) != RT_OK) break;
+        if ((s = sum_frame_times(c, fr.first, fr.second, out, true)) != RT_OK) break;
     c->pending.clear();
     c->ev_base = 0;
     return s;
@@ -510,7 +518,7 @@ extern "C" rt_status rt_trace_rays(rt_ctx *c, const rt_lights *lights, int32_t m
         c->cap_out = need;
     }
     HIPCHK(c, hipMemcpyAsync(c->d_rays[0], rays.data(), need * sizeof(RayItem), hipMemcpyHostToDevice, c->stream));
-    if ((s = run_frame(c, c->stream, nullptr, L, F, false, false, c->d_rgb, nullptr, c->d_hit, c->d_t, false, static_cast<uint32_t>(n))) != RT_OK) return s;
+    if ((s = run_frame(c, c->stream, nullptr, L, F, false, false, c->d_rgb, nullptr, c->d_hit, c->d_t, 0, static_cast<uint32_t>(n))) != RT_OK) return s;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out_rgb, c->d_rgb, need * 3 * sizeof(float), hipMemcpyDeviceToHost));
     if (out_face) HIPCHK(c, hipMemcpy(out_face, c->d_hit, need * sizeof(int32_t), hipMemcpyDeviceToHost));

@@ -6,5 +6,5 @@ echo "pytest exit $?"; tail -3 gpurun_out/pytest_quick.log
 for sc in cube dodge; do
   python bench.py --scene $sc --steps 20 --warmup 3 > gpurun_out/bench_$sc.json 2> gpurun_out/bench_$sc.err || tail -5 gpurun_out/bench_$sc.err
   python -c "
-import json; d=json.load(open('gpurun_out/bench_$sc.json')); print('$sc', d['value'], 'Mrays/s', d['ms_per_step'], 'ms', d['roofline']['ms_per_frame'], 'shadow GB/s', d['roofline']['achieved'], 'cpu', d.get('cpu_baseline',{}).get('value'))"
+import json; d=json.load(open('gpurun_out/bench_$sc.json')); print('$sc', d['value'], 'Mrays/s', d['ms_per_step'], 'ms', d['roofline']['ms_per_frame']['instrumented_frame'], 'shadow GB/s', d['roofline']['achieved'], 'cpu', d.get('cpu_baseline',{}).get('value'))"
 done
