@@ -171,6 +171,9 @@ rt_status rt_host_scene_set_model(rt_host_scene *hs, const float model[12], int3
 /* tree summary: nodes, non-empty leaves, face refs, largest leaf, depth, "lost" faces                             */
 rt_status rt_host_scene_info(const rt_host_scene *hs, int32_t out[8], float root_box[6]);
 
+/* diagnostic, host only: {chunks, cullable chunks, leaves, max chunks per leaf} of the lanes=triangles chunk bounds   */
+rt_status rt_debug_chunk_stats(const rt_scene *scene, int32_t out[4]);
+
 /* replaces: Flycamera defaults + setPerspectiveMatrix/setViewport (flyscene.cpp:46-47, flycamera.hpp:76-86)       */
 void rt_default_camera(rt_camera *cam, int32_t width, int32_t height);
 /* fly-camera yaw (rotation_Y_axis) for animation paths (flycamera.hpp:166-191)                                    */

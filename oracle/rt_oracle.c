@@ -439,6 +439,9 @@ static int classify_face(const oscene *s, const float bmin[3], const float bmax[
 
 static void node_split(oscene *s, int ni, int depth) {
     /* BoxTree::split, boxTree.cpp:88-147 */
+    /* guard (the reference has none and exhausts memory): the normalised-vector SAT can accept a face in all 8 octants,
+       so small capacities grow the tree like 8^15 on some meshes; stop at 4M nodes and flag the tree as unusable */
+    if (s->nnodes > (4 << 20)) { s->tree_capacity = -1; return; }
     s->nodes[ni].is_leaf = 0;
     float mn[3], mx[3];
     memcpy(mn, s->nodes[ni].bmin, sizeof mn); memcpy(mx, s->nodes[ni].bmax, sizeof mx);

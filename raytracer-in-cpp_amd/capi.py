@@ -89,6 +89,7 @@ _SIGNATURES = [
     ("rt_host_scene_view", C.c_int, [C.c_void_p, _P(rt_scene)]),
     ("rt_host_scene_set_model", C.c_int, [C.c_void_p, _P(C.c_float), C.c_int32]),
     ("rt_host_scene_info", C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_float)]),
+    ("rt_debug_chunk_stats", C.c_int, [_P(rt_scene), _P(C.c_int32)]),
     ("rt_default_camera", None, [_P(rt_camera), C.c_int32, C.c_int32]),
     ("rt_yaw_camera", None, [_P(rt_camera), C.c_int32, C.c_int32, C.c_float]),
     ("rt_screen_to_world", None, [_P(rt_camera), C.c_float, C.c_float, _P(C.c_float)]),

@@ -310,6 +310,10 @@ bool HostScene::face_touches(const AABB &b, int face) const {
 
 void HostScene::subdivide(int node, int depth) {
     // BoxTree::split, boxTree.cpp:88-147
+    // Guard (not in the reference, which simply runs out of memory): because clasifyFace tests NORMALISED vectors it can
+    // accept a triangle in all 8 octants at every level, so small capacities make the tree grow like 8^15 on some
+    // meshes (dodgeColorTest.obj at capacity 64).  We stop and report instead of exhausting host memory.
+    if (overflow || pool.size() > kMaxNodes || total_refs > kMaxRefs) { overflow = true; return; }
     pool[node].leaf = false;
     const V3 lo = pool[node].box.lo, hi = pool[node].box.hi;
     const float dx = (hi.x - lo.x) / 2, dy = (hi.y - lo.y) / 2, dz = (hi.z - lo.z) / 2;
@@ -341,6 +345,7 @@ void HostScene::subdivide(int node, int depth) {
         OctNode &c = pool[kids[k]];
         for (int f : parent_faces)
             if (face_touches(c.box, f)) c.faces.push_back(f);
+        total_refs += c.faces.size();
     }
     for (int k = 0; k < 8; ++k) {
         const int ci = kids[k];
@@ -355,6 +360,8 @@ void HostScene::build_octree(int cap, int depth) {
     capacity = cap;
     max_depth = depth;
     pool.clear();
+    overflow = false;
+    total_refs = 0;
     // BoundingBox(Mesh&): the running maximum starts at FLT_MIN, the smallest POSITIVE float (boundingBox.cpp:20-22)
     V3 lo{FLT_MAX, FLT_MAX, FLT_MAX}, hi{FLT_MIN, FLT_MIN, FLT_MIN};
     for (const Triangle &t : tris)

@@ -99,6 +99,10 @@ public:
     std::vector<int32_t> f_mat_id;
     std::vector<rt_material> f_mats;
     int flat_depth = 0;
+    // build guard: the reference's octree can grow exponentially (see subdivide)
+    bool overflow = false;
+    size_t total_refs = 0;
+    static constexpr size_t kMaxNodes = 4u << 20, kMaxRefs = 256u << 20;
 
 private:
     void recompute_world();

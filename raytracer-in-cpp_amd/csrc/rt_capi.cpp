@@ -3,6 +3,7 @@
 // No CPU fallback exists here: without a HIP device every entry point that needs one fails loudly.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -42,6 +43,7 @@ struct rt_ctx {
     // scene
     bool has_scene = false;
     DScene S{};
+    void *d_chunks = nullptr, *d_leaf_chunk0 = nullptr;
     void *d_nodes = nullptr, *d_tris = nullptr, *d_tri_verts = nullptr, *d_face_normal = nullptr, *d_tri_vid = nullptr,
          *d_mat_id = nullptr, *d_vert_normal = nullptr, *d_mats = nullptr;
     bool reflective = false;     // some material spawns bounce rays (illum 3,4,5,6,9)
@@ -108,7 +110,7 @@ extern "C" rt_status rt_create(rt_ctx **out, int device) {
 }
 
 static void free_scene(rt_ctx *c) {
-    void **p[] = {&c->d_nodes, &c->d_tris, &c->d_tri_verts, &c->d_face_normal, &c->d_tri_vid, &c->d_mat_id, &c->d_vert_normal, &c->d_mats};
+    void **p[] = {&c->d_chunks, &c->d_leaf_chunk0, &c->d_nodes, &c->d_tris, &c->d_tri_verts, &c->d_face_normal, &c->d_tri_vid, &c->d_mat_id, &c->d_vert_normal, &c->d_mats};
     for (void **q : p) { if (*q) (void)hipFree(*q); *q = nullptr; }
     c->has_scene = false;
 }
@@ -147,6 +149,123 @@ static rt_status upload(rt_ctx *c, void **dst, const T *src, size_t n) {
     return RT_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Conservative chunk bounds for the lanes=triangles leaf mode.
+//
+// A (ray, chunk) pair may be skipped only if NO triangle of the chunk can pass Flyscene::rayTriangleIntersection as the
+// reference evaluates it in float (flyscene.cpp:787-819).  That evaluation accepts a triangle when the barycentric
+// coordinates of the COMPUTED point P = o + t*d (projected on the triangle's plane) pass u>=0, v>=0, u+v<1.
+//   (1) P lies on the ray line up to rounding (~1e-7 * |P|), whatever the error of t.
+//   (2) When |d.n| >= tau*|d||n| (tau = 0.002), the relative error of d.n is <= 3*eps/tau ~ 9e-5 and the cancellation
+//       error of (n.A - o.n) is <= ~6e-8*(|A|+|o|), so P is within ~9e-5*(|o|+extent) of the triangle's plane.
+//   (3) With kappa = d00*d11/denom (conditioning of the reference's barycentric solve) and P within a few edge lengths,
+//       the errors of u and v are <= ~20*eps*kappa, i.e. P's projection is inside the triangle grown by 1.2e-6*kappa*edge.
+//   => an accepted hit implies the ray LINE passes within  9e-5*(|o|+extent) + 1.2e-6*kappa*edge  of the triangle.
+// So the chunk AABB is inflated by max(5e-6*kappa*edge) + 1e-3*max_edge + 1e-4*extent here (kappa <= 1e4 required), the kernel adds 4e-4*(|o|_1+extent) per ray (4x safety), and
+// the skip additionally requires |d.n| > tau*|d| for EVERY triangle of the chunk (evaluated per triangle in the kernel,
+// lanes = triangles: near-parallel rays make t, and hence P, arbitrarily wrong -- those pairs are always tested).
+// Chunks holding an ill-conditioned, degenerate, non-unit-normal or non-finite triangle are never cullable.
+// ---------------------------------------------------------------------------------------------------------------
+static uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {
+    auto spread = [](uint32_t v) {
+        v &= 0x3ffu; v = (v | (v << 16)) & 0x30000ffu; v = (v | (v << 8)) & 0x300f00fu;
+        v = (v | (v << 4)) & 0x30c30c3u; v = (v | (v << 2)) & 0x9249249u; return v;
+    };
+    return spread(x) | (spread(y) << 1) | (spread(z) << 2);
+}
+
+static void build_chunk_bounds(const rt_scene *sc, std::vector<uint32_t> &refs, std::vector<uint32_t> &leaf_chunk0,
+                               std::vector<ChunkBound> &out, float extent, bool no_cull) {
+    for (uint32_t ni = 0; ni < sc->n_nodes; ++ni) {
+        const rt_node &nd = sc->nodes[ni];
+        if (!(nd.count_flags & RT_NODE_LEAF)) continue;
+        const uint32_t cnt = nd.count_flags & 0x7fffffffu;
+        leaf_chunk0[ni] = static_cast<uint32_t>(out.size());
+        if (cnt == 0) continue;
+        uint32_t *r = refs.data() + nd.first;
+        // Morton order of the centroids inside the leaf box
+        float ext[3];
+        for (int k = 0; k < 3; ++k) ext[k] = nd.bmax[k] - nd.bmin[k];
+        std::vector<std::pair<uint32_t, uint32_t>> keyed(cnt);
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const float *v = sc->tri_verts + static_cast<size_t>(r[i]) * 9;
+            uint32_t q[3];
+            for (int k = 0; k < 3; ++k) {
+                const float cen = (v[k] + v[3 + k] + v[6 + k]) / 3.0f;
+                float u = ext[k] > 0.f ? (cen - nd.bmin[k]) / ext[k] : 0.f;
+                if (!(u > 0.f)) u = 0.f;
+                if (u > 1.f) u = 1.f;
+                q[k] = static_cast<uint32_t>(u * 1023.0f);
+            }
+            keyed[i] = {morton3(q[0], q[1], q[2]), r[i]};
+        }
+        std::sort(keyed.begin(), keyed.end());
+        for (uint32_t i = 0; i < cnt; ++i) r[i] = keyed[i].second;
+        for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {
+            const uint32_t n = cnt - c0 < 64 ? cnt - c0 : 64;
+            ChunkBound cb{};
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, max_edge = 0, bary_infl = 0;
+            bool ok = !no_cull;
+            for (uint32_t i = 0; i < n && ok; ++i) {
+                const uint32_t f = r[c0 + i];
+                const float *v = sc->tri_verts + static_cast<size_t>(f) * 9;
+                const float *nn = sc->face_normal + static_cast<size_t>(f) * 3;
+                for (int k = 0; k < 9; ++k) if (!std::isfinite(v[k])) ok = false;
+                const double nl = std::sqrt(double(nn[0]) * nn[0] + double(nn[1]) * nn[1] + double(nn[2]) * nn[2]);
+                if (!std::isfinite(nl) || std::fabs(nl - 1.0) > 1e-3) { ok = false; break; }   // Face::normal is unit unless degenerate
+                for (int k = 0; k < 3; ++k) {
+                    lo[k] = std::min(lo[k], double(std::min(v[k], std::min(v[3 + k], v[6 + k]))));
+                    hi[k] = std::max(hi[k], double(std::max(v[k], std::max(v[3 + k], v[6 + k]))));
+                }
+                // conditioning of the barycentric solve exactly as the reference sets it up (edges from vertex A)
+                double e0[3], e1[3];
+                for (int k = 0; k < 3; ++k) { e0[k] = double(v[6 + k]) - v[k]; e1[k] = double(v[3 + k]) - v[k]; }
+                const double d00 = e0[0] * e0[0] + e0[1] * e0[1] + e0[2] * e0[2], d11 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2];
+                const double d01 = e0[0] * e1[0] + e0[1] * e1[1] + e0[2] * e1[2];
+                const double den = d00 * d11 - d01 * d01;
+                if (!(d00 > 0) || !(d11 > 0) || !(den > 1e-4 * d00 * d11)) { ok = false; break; }   // kappa = d00*d11/den <= 1e4
+                const double edge = std::sqrt(std::max(d00, d11));
+                max_edge = std::max(max_edge, edge);
+                // (3): |error(u)|, |error(v)| <= ~20*eps*kappa = 1.2e-6*kappa  ->  in-plane growth 1.2e-6*kappa*edge (x4 safety)
+                bary_infl = std::max(bary_infl, 5e-6 * (d00 * d11 / den) * edge);
+            }
+            if (ok) {
+                const double infl = bary_infl + 1e-3 * max_edge + 1e-4 * extent;
+                for (int k = 0; k < 3; ++k) {
+                    cb.lo[k] = std::nextafter(static_cast<float>(lo[k] - infl), -INFINITY);
+                    cb.hi[k] = std::nextafter(static_cast<float>(hi[k] + infl), INFINITY);
+                }
+                cb.sin_guard = 0.0f;
+            }
+            if (!ok) { cb = ChunkBound{}; cb.sin_guard = 2.0f; }
+            out.push_back(cb);
+        }
+    }
+    if (out.empty()) { ChunkBound cb{}; cb.sin_guard = 2.0f; out.push_back(cb); }
+}
+
+// host-only: builds the chunk bounds of a flattened scene and reports {chunks, cullable chunks, leaves, max chunks per leaf}
+extern "C" rt_status rt_debug_chunk_stats(const rt_scene *sc, int32_t out[4]) {
+    if (!sc || !out || !sc->nodes) return RT_ERR_INVALID;
+    std::vector<uint32_t> refs(sc->face_refs, sc->face_refs + sc->n_face_refs);
+    std::vector<uint32_t> leaf_chunk0(sc->n_nodes, 0u);
+    std::vector<ChunkBound> cbs;
+    float extent = 0.f;
+    for (size_t i = 0; i < static_cast<size_t>(sc->n_faces) * 9; ++i) extent = std::fmax(extent, std::fabs(sc->tri_verts[i]));
+    build_chunk_bounds(sc, refs, leaf_chunk0, cbs, extent, false);
+    int cullable = 0, leaves = 0, maxc = 0;
+    for (const ChunkBound &cb : cbs) cullable += cb.sin_guard < 1.5f ? 1 : 0;
+    for (uint32_t i = 0; i < sc->n_nodes; ++i)
+        if (sc->nodes[i].count_flags & RT_NODE_LEAF) {
+            ++leaves;
+            const int nc = static_cast<int>(((sc->nodes[i].count_flags & 0x7fffffffu) + 63u) / 64u);
+            if (nc > maxc) maxc = nc;
+        }
+    out[0] = static_cast<int32_t>(cbs.size()); out[1] = cullable; out[2] = leaves; out[3] = maxc;
+    return RT_OK;
+}
+
 extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     if (!c) return RT_ERR_INVALID;
     if (!sc || !sc->nodes || sc->n_nodes == 0 || !sc->materials || sc->n_materials == 0) { c->err = "rt_upload_scene: empty scene"; return RT_ERR_INVALID; }
@@ -175,11 +294,22 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
             if (sc->tri_vid[f * 3 + k] >= sc->n_vert_normals) { c->err = "rt_upload_scene: vertex id outside vert_normal"; return RT_ERR_INVALID; }
     }
 
+    // Leaf face lists are re-ordered along a Morton curve (the order inside a leaf cannot change any result: closest
+    // hit is a minimum with a face-id tie-break, shadow rays are any-hit), so that every run of 64 references -- one
+    // `chunk` of the lanes=triangles mode -- is spatially compact and its conservative bound is tight.
+    std::vector<uint32_t> refs(sc->face_refs, sc->face_refs + sc->n_face_refs);
+    std::vector<uint32_t> leaf_chunk0(sc->n_nodes, 0u);
+    std::vector<ChunkBound> cbs;
+    float extent = 0.f;
+    for (size_t i = 0; i < static_cast<size_t>(sc->n_faces) * 9; ++i) extent = std::fmax(extent, std::fabs(sc->tri_verts[i]));
+    const bool no_cull = std::getenv("RT_NO_CULL") != nullptr;
+    build_chunk_bounds(sc, refs, leaf_chunk0, cbs, extent, no_cull);
+
     // leaf-ordered triangle records: the per-triangle constants of rayTriangleIntersection (flyscene.cpp:787-811),
     // evaluated once with the same float operations the reference performs on every call
     std::vector<TriRec> recs(sc->n_face_refs);
     for (uint32_t i = 0; i < sc->n_face_refs; ++i) {
-        const uint32_t f = sc->face_refs[i];
+        const uint32_t f = refs[i];
         const float *v = sc->tri_verts + static_cast<size_t>(f) * 9;
         const float *n = sc->face_normal + static_cast<size_t>(f) * 3;
         TriRec &r = recs[i];
@@ -206,6 +336,8 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     rt_status st;
     if ((st = upload(c, &c->d_nodes, sc->nodes, sc->n_nodes)) != RT_OK) return st;
     if ((st = upload(c, &c->d_tris, recs.data(), recs.size())) != RT_OK) return st;
+    if ((st = upload(c, &c->d_chunks, cbs.data(), cbs.size())) != RT_OK) return st;
+    if ((st = upload(c, &c->d_leaf_chunk0, leaf_chunk0.data(), leaf_chunk0.size())) != RT_OK) return st;
     if ((st = upload(c, &c->d_tri_verts, sc->tri_verts, static_cast<size_t>(sc->n_faces) * 9)) != RT_OK) return st;
     if ((st = upload(c, &c->d_face_normal, sc->face_normal, static_cast<size_t>(sc->n_faces) * 3)) != RT_OK) return st;
     if ((st = upload(c, &c->d_tri_vid, sc->tri_vid, static_cast<size_t>(sc->n_faces) * 3)) != RT_OK) return st;
@@ -214,6 +346,9 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     if ((st = upload(c, &c->d_mats, sc->materials, sc->n_materials)) != RT_OK) return st;
     c->S.nodes = static_cast<const rt_node *>(c->d_nodes);
     c->S.leaf_tris = static_cast<const TriRec *>(c->d_tris);
+    c->S.chunks = static_cast<const ChunkBound *>(c->d_chunks);
+    c->S.leaf_chunk0 = static_cast<const uint32_t *>(c->d_leaf_chunk0);
+    c->S.extent = extent;
     c->S.tri_verts = static_cast<const float *>(c->d_tri_verts);
     c->S.face_normal = static_cast<const float *>(c->d_face_normal);
     c->S.tri_vid = static_cast<const uint32_t *>(c->d_tri_vid);
@@ -349,8 +484,8 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
     out->pixels = F.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;
 #ifdef RT_PROFILE
     if (!counted) {
-        std::fprintf(stderr, "RT_PROFILE ray-mode steps %llu useful %llu | tri-mode steps %llu useful %llu | box steps %llu useful %llu | leaves ray %llu tri %llu live-at-tri %llu\n",
-                     h.prof[0], h.prof[1], h.prof[2], h.prof[3], h.prof[4], h.prof[5], h.prof[6], h.prof[7], h.prof[8]);
+        std::fprintf(stderr, "RT_PROFILE ray-mode steps %llu useful %llu | tri-mode steps %llu useful %llu | box steps %llu useful %llu | leaves ray %llu tri %llu live-at-tri %llu | culled pairs %llu guard-kept %llu\n",
+                     h.prof[0], h.prof[1], h.prof[2], h.prof[3], h.prof[4], h.prof[5], h.prof[6], h.prof[7], h.prof[8], h.prof[12], h.prof[13]);
         std::fprintf(stderr, "RT_PROFILE shadow units %llu: cycles max %llu mean %.0f; log2 histogram:", h.prof[11], h.prof[9], h.prof[11] ? double(h.prof[10]) / double(h.prof[11]) : 0.0);
         for (int b = 8; b <= 30; ++b) std::fprintf(stderr, " [2^%d]=%llu", b, h.prof[16 + b]);
         std::fprintf(stderr, "\n");
@@ -561,6 +696,13 @@ extern "C" rt_status rt_host_scene_load(const char *obj_path, int32_t leaf_capac
         return RT_ERR_IO;
     }
     h->hs.build_octree(leaf_capacity, max_depth);
+    if (h->hs.overflow) {
+        std::fprintf(stderr, "rt_mi355x: the reference's octree construction does not terminate in bounded memory for this mesh at "
+                             "capacity %d (more than %zu nodes / %zu face references); choose a larger capacity\n",
+                     leaf_capacity, HostScene::kMaxNodes, HostScene::kMaxRefs);
+        delete h;
+        return RT_ERR_UNSUPPORTED;
+    }
     h->hs.flatten();
     *out = h;
     return RT_OK;
@@ -577,7 +719,7 @@ extern "C" rt_status rt_host_scene_view(const rt_host_scene *hs, rt_scene *out) 
 extern "C" rt_status rt_host_scene_set_model(rt_host_scene *hs, const float model[12], int32_t rebuild_tree) {
     if (!hs || !model) return RT_ERR_INVALID;
     hs->hs.set_model(model, rebuild_tree != 0);
-    return RT_OK;
+    return hs->hs.overflow ? RT_ERR_UNSUPPORTED : RT_OK;
 }
 
 extern "C" rt_status rt_host_scene_info(const rt_host_scene *hs, int32_t out[8], float root_box[6]) {

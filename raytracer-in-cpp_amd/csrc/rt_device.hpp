@@ -35,6 +35,19 @@ struct alignas(16) TriRec {
 };
 static_assert(sizeof(TriRec) == 80, "TriRec must be 80 bytes");
 
+// Conservative bound of one 64-triangle chunk of a leaf (lanes = triangles mode).  A ray may skip the chunk only when
+// it is provably impossible for ANY triangle of the chunk to pass rayTriangleIntersection AS THE REFERENCE COMPUTES
+// IT IN FLOAT (see rt_capi.cpp: build_chunk_bounds for the error analysis): the ray line misses the inflated AABB
+// AND the ray is not within the guard angle of being parallel to any triangle plane of the chunk (checked per triangle
+// in the kernel: |d.n| > tau |d|).
+struct alignas(16) ChunkBound {
+    float lo[3], hi[3];      // AABB of the chunk's triangles, inflated
+    float ax, ay, az;        // unused (reserved)
+    float sin_guard;         // 0: chunk may be culled; 2: never (ill-conditioned / degenerate / non-finite triangle inside)
+    float pad0, pad1;
+};
+static_assert(sizeof(ChunkBound) == 48, "ChunkBound must be 48 bytes");
+
 struct alignas(16) RayItem {     // a bounce ray (level >= 1) or an rt_trace_rays input ray
     float ox, oy, oz, dx;
     float dy, dz, lx, ly;
@@ -69,6 +82,9 @@ enum : uint32_t {
 struct DScene {
     const rt_node *nodes;
     const TriRec *leaf_tris;
+    const ChunkBound *chunks;          // per leaf: ceil(count/64) bounds starting at leaf_chunk0[node]
+    const uint32_t *leaf_chunk0;
+    float extent;                      // max |coordinate| of the scene (for the per-ray slab padding)
     const float *tri_verts;
     const float *face_normal;
     const uint32_t *tri_vid;

@@ -155,7 +155,11 @@ __device__ __forceinline__ float lane_f(float v, int src_lane) {
 #ifdef RT_PROFILE
 // profiling build: wave-level step counters, flushed with one atomic per leaf/inner visit (slow, diagnostic only)
 __device__ unsigned long long *g_prof = nullptr;
+#ifdef RT_PROFILE_STEPS
 #define RT_PROF_ADD(lane, idx, val) do { const unsigned long long pv_ = static_cast<unsigned long long>(val); if ((lane) == 0 && g_prof) atomicAdd(&g_prof[(idx)], pv_); } while (0)
+#else
+#define RT_PROF_ADD(lane, idx, val) do { } while (0)   // RT_PROFILE alone: only the per-unit cycle histogram (undistorted)
+#endif
 #else
 #define RT_PROF_ADD(lane, idx, val) do { } while (0)
 #endif
@@ -166,10 +170,12 @@ __device__ unsigned long long *g_prof = nullptr;
 
 #define RT_COST_RAY_MODE 45u      // per triangle, lanes = rays (all 64 lanes step through every triangle)
 #define RT_COST_TRI_MODE 58u      // per (active ray, 64-triangle chunk), lanes = triangles
+#define RT_COST_CHUNK_TEST 30u    // per chunk: conservative bound test for all 64 rays at once
 
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
-                                            const WaveStack stk, const int lane, bool in_root,
+                                            const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
+                                            const float extent, const WaveStack stk, const int lane, bool in_root,
                                             const float ox, const float oy, const float oz,      // ray origin
                                             const float dx, const float dy, const float dz,      // triangle-test direction
                                             const float bx, const float by, const float bz,      // box-test direction (dest - origin)
@@ -198,8 +204,10 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
         if (nd.count_flags & RT_NODE_LEAF) {
             if (COUNT && mine) cnt_ref += cnt;
             const TriRec *__restrict__ T = tris + nd.first;
-            const uint32_t chunks = (cnt + 63u) >> 6;
-            const bool tri_mode = static_cast<uint32_t>(__popcll(live)) * chunks * RT_COST_TRI_MODE < cnt * RT_COST_RAY_MODE;
+            const uint32_t nchunk = (cnt + 63u) >> 6;
+            // lanes=triangles estimate: one bound test per chunk + live rays x the share of chunks a ray cannot skip
+            const bool tri_mode = nchunk * RT_COST_CHUNK_TEST + static_cast<uint32_t>(__popcll(live)) * ((nchunk + 2u) / 3u) * RT_COST_TRI_MODE
+                                  < cnt * RT_COST_RAY_MODE;
             RT_PROF_ADD(lane, tri_mode ? 7 : 6, 1);
             if (tri_mode) {
                 RT_PROF_ADD(lane, 8, __popcll(live));
@@ -208,20 +216,48 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                 // its triangle against that ray.  A ballot reports the hits: exact early-out per ray for shadow rays,
                 // and a scalar pick of the (t, face) minimum for closest hit.  No per-triangle memory round trip.
                 unsigned long long occ_new = 0ull;
+                const ChunkBound *__restrict__ cbounds = chunks + leaf_chunk0[ni];
+                // per-ray quantities of the conservative chunk test (approximate arithmetic is fine: they only ever SKIP
+                // work); computed per leaf visit so that scenes that never take this mode (the cube) pay nothing
+                const float q_len = dx * dx + dy * dy + dz * dz;
+                const float guard_len = 0.002f * 1.001f * sqrtf(q_len);           // tau * |d|, tau = 0.002
+                const float idx_ = fabsf(dx) > 1e-30f ? 1.0f / dx : copysignf(1e30f, dx);   // never inf: no inf*0 NaNs
+                const float idy_ = fabsf(dy) > 1e-30f ? 1.0f / dy : copysignf(1e30f, dy);
+                const float idz_ = fabsf(dz) > 1e-30f ? 1.0f / dz : copysignf(1e30f, dz);
+                const float slab_pad = 4e-4f * (fabsf(ox) + fabsf(oy) + fabsf(oz) + extent);
                 TriRec tr = T[static_cast<uint32_t>(lane) < cnt ? static_cast<uint32_t>(lane) : 0u];
                 for (uint32_t c0 = 0; c0 < cnt; c0 += 64u) {
                     const uint32_t n = cnt - c0 < 64u ? cnt - c0 : 64u;
                     const bool has = static_cast<uint32_t>(lane) < n && !(ANY && (tr.flags & 1u));
                     const uint32_t nx = c0 + 64u + static_cast<uint32_t>(lane);
                     const TriRec nxt = T[nx < cnt ? nx : 0u];                      // prefetch (uniformly skipped work is cheap)
-                    unsigned long long todo = live;
+                    // conservative chunk test, step 1 (lanes = rays): which live rays' LINES miss the inflated chunk box
+                    unsigned long long todo = live, boxmiss = 0ull;
+                    {
+                        const ChunkBound cb = cbounds[c0 >> 6];
+                        if (cb.sin_guard < 1.5f) {
+                            const float t0x = (cb.lo[0] - slab_pad - ox) * idx_, t1x = (cb.hi[0] + slab_pad - ox) * idx_;
+                            const float t0y = (cb.lo[1] - slab_pad - oy) * idy_, t1y = (cb.hi[1] + slab_pad - oy) * idy_;
+                            const float t0z = (cb.lo[2] - slab_pad - oz) * idz_, t1z = (cb.hi[2] + slab_pad - oz) * idz_;
+                            const float tin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+                            const float tout = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+                            boxmiss = __ballot(tin > tout) & live;
+                        }
+                    }
                     while (todo != 0ull) {
                         const int r = static_cast<int>(__builtin_ctzll(todo));
                         todo &= todo - 1ull;
-                        const float rox = lane_f(ox, r), roy = lane_f(oy, r), roz = lane_f(oz, r);
                         const float rdx = lane_f(dx, r), rdy = lane_f(dy, r), rdz = lane_f(dz, r);
                         // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 (same operations as the ray-lane form)
                         const float dn = dot3(rdx, rdy, rdz, tr.nx, tr.ny, tr.nz);
+                        if ((boxmiss >> r) & 1ull) {
+                            // step 2 (lanes = triangles): the skip is only sound when the ray is not within the guard angle
+                            // of being parallel to ANY plane of the chunk (|d.n| > tau |d|, unit normals): near-parallel
+                            // pairs make the reference's t, hence its hit point, arbitrarily wrong and are always tested.
+                            if (__ballot(has && !(fabsf(dn) > lane_f(guard_len, r))) == 0ull) { RT_PROF_ADD(lane, 12, 1); continue; }
+                            RT_PROF_ADD(lane, 13, 1);
+                        }
+                        const float rox = lane_f(ox, r), roy = lane_f(oy, r), roz = lane_f(oz, r);
                         const float t = (tr.nA - dot3(rox, roy, roz, tr.nx, tr.ny, tr.nz)) / dn;
                         const float v2x = (rox + t * rdx) - tr.ax, v2y = (roy + t * rdy) - tr.ay, v2z = (roz + t * rdz) - tr.az;
                         const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
@@ -354,6 +390,7 @@ __device__ __forceinline__ void light_sample(const DLights &L, const float px, c
 // ======================================================================================================
 template <bool PRIMARY, bool COUNT>
 __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
+                                                          const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                                           const DScene S, const DCam cam, const DLights L, const DFrame F,
                                                           const int level, const int ctr_slot,
                                                           const RayItem *__restrict__ rays_in, ShadeItem *__restrict__ items,
@@ -416,7 +453,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
         float best_t = 3.402823466e+38f;
         int best_f = -1;
         bool dummy = false;
-        packet_walk<false, COUNT>(nodes, tris, stk, lane, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz, best_t, best_f, dummy, c_box, c_ref);
+        packet_walk<false, COUNT>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz, best_t, best_f, dummy, c_box, c_ref);
         const bool hit = valid && (best_f >= 0);
         const float hx = ox + best_t * dx, hy = oy + best_t * dy, hz = oz + best_t * dz;   // flyscene.cpp:695
 
@@ -434,7 +471,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
                 const bool sroot = act && box_hit(root.bmin, px, py, pz, sdx, sdy, sdz);
                 float t_unused = 0.f; int f_unused = -1;
                 bool occ = false;
-                packet_walk<true, COUNT>(nodes, tris, stk, lane, sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz, t_unused, f_unused, occ, c_box, c_ref);
+                packet_walk<true, COUNT>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz, t_unused, f_unused, occ, c_box, c_ref);
                 lit = lit || (act && !occ);
             }
         }
@@ -481,6 +518,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
 // ======================================================================================================
 template <bool COUNT>
 __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
+                                                          const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                                            const DScene S, const DLights L, const int level, const int ctr_slot,
                                                            const int lslots, const ShadeItem *__restrict__ items,
                                                            Control *__restrict__ ctl, unsigned long long *__restrict__ vis) {
@@ -531,7 +569,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restr
         const bool sroot = valid && box_hit(root.bmin, sx, sy, sz, ddx, ddy, ddz);
         float t_unused = 0.f; int f_unused = -1;
         bool occ = false;
-        packet_walk<true, COUNT>(nodes, tris, stk, lane, sroot, sx, sy, sz, ddx, ddy, ddz, ddx, ddy, ddz, t_unused, f_unused, occ, c_box, c_ref);
+        packet_walk<true, COUNT>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, sroot, sx, sy, sz, ddx, ddy, ddz, ddx, ddy, ddz, t_unused, f_unused, occ, c_box, c_ref);
         const unsigned long long vm = __ballot(valid && !occ);
         if (N <= 64u) {
             if (s_in == 0u && slot < G && g < groups) {
@@ -758,6 +796,7 @@ __global__ __launch_bounds__(256) void k_resolve(const DFrame F, const float4 *_
 // lightStrikes on explicit segments (rt_light_strikes): lane = segment light[i] -> hit[i]
 // ======================================================================================================
 __global__ __launch_bounds__(RT_WAVES * 64) void k_segments(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
+                                                          const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                                              const DScene S, const int n, const float *__restrict__ hit,
                                                              const float *__restrict__ light, uint8_t *__restrict__ vis) {
     __shared__ uint4 s_stage[RT_WAVES * RT_STAGE_TRIS * 5];
@@ -775,7 +814,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_segments(const rt_node *__res
         const float ddx = hit[j * 3] - px, ddy = hit[j * 3 + 1] - py, ddz = hit[j * 3 + 2] - pz;
         const bool sroot = valid && box_hit(root.bmin, px, py, pz, ddx, ddy, ddz);
         float t_unused = 0.f; int f_unused = -1; bool occ = false; uint32_t c0 = 0, c1 = 0;
-        packet_walk<true, false>(nodes, tris, stk, lane, sroot, px, py, pz, ddx, ddy, ddz, ddx, ddy, ddz, t_unused, f_unused, occ, c0, c1);
+        packet_walk<true, false>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, sroot, px, py, pz, ddx, ddy, ddz, ddx, ddy, ddz, t_unused, f_unused, occ, c0, c1);
         if (valid) vis[i] = occ ? 0 : 1;
     }
 }
@@ -805,19 +844,19 @@ void launch_trace(bool primary, bool count, int grid, hipStream_t st, const DSce
                   int level, int slot, const RayItem *rays_in, ShadeItem *items, Control *ctl, float4 *rec, int32_t *out_hit, float *out_t) {
     const dim3 g(grid), b(RT_WAVES * 64);
     if (primary) {
-        if (count) hipLaunchKernelGGL((k_trace<true, true>), g, b, 0, st, S.nodes, S.leaf_tris, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
-        else hipLaunchKernelGGL((k_trace<true, false>), g, b, 0, st, S.nodes, S.leaf_tris, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
+        if (count) hipLaunchKernelGGL((k_trace<true, true>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
+        else hipLaunchKernelGGL((k_trace<true, false>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
     } else {
-        if (count) hipLaunchKernelGGL((k_trace<false, true>), g, b, 0, st, S.nodes, S.leaf_tris, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
-        else hipLaunchKernelGGL((k_trace<false, false>), g, b, 0, st, S.nodes, S.leaf_tris, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
+        if (count) hipLaunchKernelGGL((k_trace<false, true>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
+        else hipLaunchKernelGGL((k_trace<false, false>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
     }
 }
 
 void launch_shadow(bool count, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
                    const ShadeItem *items, Control *ctl, unsigned long long *vis) {
     const dim3 g(grid), b(RT_WAVES * 64);
-    if (count) hipLaunchKernelGGL((k_shadow<true>), g, b, 0, st, S.nodes, S.leaf_tris, S, L, level, slot, lslots, items, ctl, vis);
-    else hipLaunchKernelGGL((k_shadow<false>), g, b, 0, st, S.nodes, S.leaf_tris, S, L, level, slot, lslots, items, ctl, vis);
+    if (count) hipLaunchKernelGGL((k_shadow<true>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, L, level, slot, lslots, items, ctl, vis);
+    else hipLaunchKernelGGL((k_shadow<false>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, L, level, slot, lslots, items, ctl, vis);
 }
 
 void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level, int slot, int lslots,
@@ -830,7 +869,7 @@ void launch_resolve(int grid, hipStream_t st, const DFrame &F, const float4 *rec
 }
 
 void launch_segments(int grid, hipStream_t st, const DScene &S, int n, const float *hit, const float *light, uint8_t *vis) {
-    hipLaunchKernelGGL(k_segments, dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S, n, hit, light, vis);
+    hipLaunchKernelGGL(k_segments, dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, n, hit, light, vis);
 }
 
 }  // namespace rtamd

@@ -128,3 +128,32 @@ def test_bad_inputs_are_rejected(rt, scenes, tmp_path):
     p = rt.make_params(64, 48, row0=0, row1=48, stripe=8, rank=1, nranks=3)
     rows = [y for y in range(48) if (y // 8) % 3 == 1]
     assert lib.rt_local_rows(C.byref(p)) == len(rows)
+
+
+def test_octree_growth_guard_and_lost_faces(rt, oracle, scenes):
+    """Capacity 100 on dodge: depth-9 tree with 'lost' faces (children holding exactly `capacity` faces are neither leaf
+    nor split, boxTree.cpp:140-145) -- product == oracle.  Capacity 64 makes the reference's construction explode
+    (normalised-vector SAT accepts faces in every octant): the product refuses instead of exhausting memory."""
+    import ctypes as C
+    path = os.path.join(scenes, "dodgeColorTest.obj")
+    hs = rt.HostScene(path, leaf_capacity=100, max_depth=15)
+    info = hs.info()
+    assert info["depth"] >= 6 and info["lost_nodes"] >= 1 and info["unreachable_faces"] >= 1
+    osc = oracle.load_scene(path, capacity=100, maxdepth=15)
+    want = flat_tree_from_oracle(osc)
+    a = hs.arrays()
+    assert len(want) == a["node_box"].shape[0]
+    for i, (kind, box, payload) in enumerate(want):
+        assert np.array_equal(a["node_box"][i].view(np.uint32), box.view(np.uint32))
+        if kind == "leaf":
+            first, cnt = int(a["node_first"][i]), int(a["node_count_flags"][i]) & 0x7FFFFFFF
+            assert np.array_equal(a["face_refs"][first:first + cnt].astype(np.int32), payload)
+        else:
+            assert (int(a["node_count_flags"][i]) & 0x7FFFFFFF) == payload
+    lib = rt.load_library()
+    out = (C.c_int32 * 4)()
+    assert lib.rt_debug_chunk_stats(C.byref(hs.view), out) == 0 and out[0] >= info["leaves"] and out[2] == info["leaves"]
+    h = C.c_void_p()
+    assert lib.rt_host_scene_load(path.encode(), 64, 15, C.byref(h)) == rt.capi.RT_ERR_UNSUPPORTED
+    hs.close()
+    osc.close()
