@@ -16,15 +16,15 @@
 #include "rt_mi355x.h"
 
 namespace rtamd {
-void launch_trace(bool primary, bool count, int grid, hipStream_t st, const DScene &S, const DCam &cam, const DLights &L, const DFrame &F,
+void launch_trace(bool primary, bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DCam &cam, const DLights &L, const DFrame &F,
                   int level, int slot, const RayItem *rays_in, ShadeItem *items, Control *ctl, float4 *rec, int32_t *out_hit, float *out_t);
-void launch_shadow(bool count, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
+void launch_shadow(bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
                    const ShadeItem *items, Control *ctl, unsigned long long *vis);
 void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level, int slot, int lslots,
                   const ShadeItem *items, Control *ctl, const unsigned long long *vis, float4 *rec, float *fres, RayItem *rays_out);
 void launch_resolve(int grid, hipStream_t st, const DFrame &F, const float4 *rec, const float *fres, float *out_rgb, uint8_t *out_u8);
 void launch_segments(int grid, hipStream_t st, const DScene &S, int n, const float *hit, const float *light, uint8_t *vis);
-void query_occupancy(int *trace_primary, int *trace_rays, int *shadow, int *shade);
+void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow, int *shade);
 void launch_set_prof(hipStream_t st, Control *ctl);
 }  // namespace rtamd
 
@@ -47,6 +47,8 @@ struct rt_ctx {
     void *d_nodes = nullptr, *d_tris = nullptr, *d_tri_verts = nullptr, *d_face_normal = nullptr, *d_tri_vid = nullptr,
          *d_mat_id = nullptr, *d_vert_normal = nullptr, *d_mats = nullptr;
     bool reflective = false;     // some material spawns bounce rays (illum 3,4,5,6,9)
+    bool flat = false;           // the root is a small leaf (cube.obj): specialised stack-free kernels
+    int grid_mult = 1;
     // frame buffers
     size_t cap_pix = 0;
     int cap_levels = 0;
@@ -98,10 +100,9 @@ extern "C" rt_status rt_create(rt_ctx **out, int device) {
     if (hipSetDevice(device) != hipSuccess) { delete c; return RT_ERR_NO_DEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    query_occupancy(&c->occ_trace_primary, &c->occ_trace_rays, &c->occ_shadow, &c->occ_shade);
     if (const char *gm = std::getenv("RT_GRID_MULT")) {          // tuning knob: grid = CUs x residency x mult
         const int m = std::atoi(gm);
-        if (m > 0 && m <= 64) { c->occ_trace_primary *= m; c->occ_trace_rays *= m; c->occ_shadow *= m; c->occ_shade *= m; }
+        if (m > 0 && m <= 64) c->grid_mult = m;
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RT_ERR_HIP; }
     if (hipMalloc(reinterpret_cast<void **>(&c->d_ctl), sizeof(Control)) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return RT_ERR_HIP; }
@@ -358,6 +359,13 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     std::memcpy(c->S.model, sc->model, sizeof(float) * 12);
     c->S.n_nodes = sc->n_nodes;
     c->S.n_faces = sc->n_faces;
+    c->flat = (sc->nodes[0].count_flags & RT_NODE_LEAF) && (sc->nodes[0].count_flags & 0x7fffffffu) <= 64u;
+    query_occupancy(c->flat, &c->occ_trace_primary, &c->occ_trace_rays, &c->occ_shadow, &c->occ_shade);
+    // k_trace uses static tile striding: with more than ~4 blocks/CU a wave owns so few tiles (32,400 tiles at 1080p)
+    // that heavy object tiles no longer average out (measured 0.26 ms at 4 blocks/CU vs 0.38 ms at 7-8)
+    if (c->occ_trace_primary > 4) c->occ_trace_primary = 4;
+    if (c->occ_trace_rays > 4) c->occ_trace_rays = 4;
+    c->occ_trace_primary *= c->grid_mult; c->occ_trace_rays *= c->grid_mult; c->occ_shadow *= c->grid_mult; c->occ_shade *= c->grid_mult;
     c->has_scene = true;
     return RT_OK;
 }
@@ -438,10 +446,10 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
         float4 *rec_l = c->d_rec + static_cast<size_t>(level) * F.npix;
         float *fres_l = c->d_fres + static_cast<size_t>(level) * F.npix;
         const bool prim = primary && level == 0;
-        launch_trace(prim, count, c->cus * (prim ? c->occ_trace_primary : c->occ_trace_rays), st, c->S, cam0, L, F, level, 3 * level, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
+        launch_trace(prim, count, c->flat, c->cus * (prim ? c->occ_trace_primary : c->occ_trace_rays), st, c->S, cam0, L, F, level, 3 * level, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
                      level == 0 ? d_hit : nullptr, level == 0 ? d_t : nullptr);
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
-        launch_shadow(count, c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, c->d_items, c->d_ctl, c->d_vis);
+        launch_shadow(count, c->flat, c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, c->d_items, c->d_ctl, c->d_vis);
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
         launch_shade(c->cus * c->occ_shade, st, c->S, L, F, level, 3 * level + 2, lslots, c->d_items, c->d_ctl, c->d_vis, rec_l, fres_l, c->d_rays[(level + 1) & 1]);
         if (timed == 1) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));

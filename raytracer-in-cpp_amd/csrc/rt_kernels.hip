@@ -147,6 +147,29 @@ struct WaveStack {
 //                  (not illum 9) has 1e-5 < t < 0.98 -- so a lane may stop at its first occluder (exact).
 //   COUNT = true : no early-out; counts boxIntersect calls / leaf face references with the reference's semantics
 //                  (every pushed node is box-tested again when popped, boxTree.cpp:158,164).
+// ---- explicit scalar load of a wave-uniform TriRec ----------------------------------------------------------------
+// hipcc only selects s_load for a uniform global load when it can prove the memory unclobbered, which depends on code
+// shape (it fell back to 64-lane global_loads in the flat kernels, and split the record into three dependent waits
+// elsewhere).  The records are read-only for the kernel's lifetime, so the load is spelt out: s_load_dwordx16 +
+// s_load_dwordx4 + ONE s_waitcnt inside a single asm statement (no output is visible before its wait; an asynchronous
+// issue/wait split was tried and is unsafe: the compiler may copy the destination SGPRs before the data lands).
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ TriRec tri_load_uniform(const TriRec *p) {
+    u32x16 lo;
+    u32x4 hi;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(lo), "=&s"(hi) : "s"(p) : "memory");
+    TriRec t;
+    t.ax = __uint_as_float(lo[0]); t.ay = __uint_as_float(lo[1]); t.az = __uint_as_float(lo[2]);
+    t.e0x = __uint_as_float(lo[3]); t.e0y = __uint_as_float(lo[4]); t.e0z = __uint_as_float(lo[5]);
+    t.e1x = __uint_as_float(lo[6]); t.e1y = __uint_as_float(lo[7]); t.e1z = __uint_as_float(lo[8]);
+    t.nx = __uint_as_float(lo[9]); t.ny = __uint_as_float(lo[10]); t.nz = __uint_as_float(lo[11]);
+    t.nA = __uint_as_float(lo[12]); t.d00 = __uint_as_float(lo[13]); t.d01 = __uint_as_float(lo[14]); t.d11 = __uint_as_float(lo[15]);
+    t.inv_denom = __uint_as_float(hi[0]); t.face = hi[1]; t.flags = hi[2]; t.pad = 0u;
+    return t;
+}
+
 __device__ __forceinline__ float lane_f(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
@@ -320,9 +343,8 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                     }
                 };
                 if (cnt <= RT_SCALAR_LEAF_MAX) {
-                    // (a one-record-ahead cur/nxt pipeline was measured 15 % SLOWER here: 20 s_mov copies + SGPR pressure)
                     for (uint32_t k = 0; k < cnt; ++k) {
-                        const TriRec tr = T[k];
+                        const TriRec tr = tri_load_uniform(T + k);
                         RT_PROF_ADD(lane, 0, 1); RT_PROF_ADD(lane, 1, __popcll(__ballot(mine)));
                         test_lane(tr);
                     }
@@ -366,6 +388,59 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
     }
 }
 
+// Flat scenes (the root is itself a small leaf -- cube.obj: 1 node, 12 triangles): no stack, no LDS, no mode choice;
+// every ray that passes the root test steps through the same wave-uniform triangle list (scalar loads).
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void flat_walk(const rt_node &root, const TriRec *__restrict__ tris, bool in_root,
+                                          const float ox, const float oy, const float oz,
+                                          const float dx, const float dy, const float dz,
+                                          float &best_t, int &best_f, bool &occluded, uint32_t &cnt_box, uint32_t &cnt_ref) {
+    if (__ballot(in_root) == 0ull) return;
+    const uint32_t cnt = root.count_flags & 0x7fffffffu;
+    if (COUNT && in_root) { cnt_box += 1; cnt_ref += cnt; }
+    const TriRec *__restrict__ T = tris + root.first;
+    bool mine = in_root;
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const TriRec tr = tri_load_uniform(T + k);
+        if (mine && !(ANY && (tr.flags & 1u))) {
+            // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819
+            const float dn = dot3(dx, dy, dz, tr.nx, tr.ny, tr.nz);
+            if (dn != 0) {
+                const float t = (tr.nA - dot3(ox, oy, oz, tr.nx, tr.ny, tr.nz)) / dn;
+                const float v2x = (ox + t * dx) - tr.ax, v2y = (oy + t * dy) - tr.ay, v2z = (oz + t * dz) - tr.az;
+                const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
+                const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
+                const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
+                const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
+                if ((u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f)) {
+                    if (ANY) {
+                        if (t < 0.98f) occluded = true;
+                    } else if (t < best_t || (t == best_t && static_cast<int>(tr.face) < best_f)) {
+                        best_t = t;
+                        best_f = static_cast<int>(tr.face);
+                    }
+                }
+            }
+        }
+        if (ANY && !COUNT && (k & 7u) == 7u) {
+            mine = mine && !occluded;
+            if (__ballot(mine) == 0ull) break;
+        }
+    }
+}
+
+template <bool ANY, bool COUNT, bool FLAT>
+__device__ __forceinline__ void walk(const rt_node &root, const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
+                                     const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
+                                     const float extent, const WaveStack stk, const int lane, bool in_root,
+                                     const float ox, const float oy, const float oz, const float dx, const float dy, const float dz,
+                                     const float bx, const float by, const float bz,
+                                     float &best_t, int &best_f, bool &occluded, uint32_t &cnt_box, uint32_t &cnt_ref) {
+    if (FLAT) flat_walk<ANY, COUNT>(root, tris, in_root, ox, oy, oz, dx, dy, dz, best_t, best_f, occluded, cnt_box, cnt_ref);
+    else packet_walk<ANY, COUNT>(nodes, tris, chunks, leaf_chunk0, extent, stk, lane, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz,
+                                 best_t, best_f, occluded, cnt_box, cnt_ref);
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
@@ -388,7 +463,7 @@ __device__ __forceinline__ void light_sample(const DLights &L, const float px, c
 // K1: closest hit + light-centre visibility.  PRIMARY: fused primary-ray generation (Camera::screenToWorld)
 // and root-AABB cull of raytraceScene's serial loop (flyscene.cpp:573-598); otherwise reads compacted rays.
 // ======================================================================================================
-template <bool PRIMARY, bool COUNT>
+template <bool PRIMARY, bool COUNT, bool FLAT>
 __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
                                                           const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                                           const DScene S, const DCam cam, const DLights L, const DFrame F,
@@ -453,8 +528,8 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
         float best_t = 3.402823466e+38f;
         int best_f = -1;
         bool dummy = false;
-        packet_walk<false, COUNT>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz, best_t, best_f, dummy, c_box, c_ref);
-        const bool hit = valid && (best_f >= 0);
+        walk<false, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz, best_t, best_f, dummy, c_box, c_ref);
+        const bool hit = valid && (best_f >= 0) && (static_cast<uint32_t>(best_f) < S.n_faces);
         const float hx = ox + best_t * dx, hy = oy + best_t * dy, hz = oz + best_t * dz;   // flyscene.cpp:695
 
         // lightStrikes(hitPoint, lights): one segment per light CENTRE (flyscene.cpp:700)
@@ -471,7 +546,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
                 const bool sroot = act && box_hit(root.bmin, px, py, pz, sdx, sdy, sdz);
                 float t_unused = 0.f; int f_unused = -1;
                 bool occ = false;
-                packet_walk<true, COUNT>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz, t_unused, f_unused, occ, c_box, c_ref);
+                walk<true, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz, t_unused, f_unused, occ, c_box, c_ref);
                 lit = lit || (act && !occ);
             }
         }
@@ -516,7 +591,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
 // One wave = the N samples of one (hit, light) pair (N = 64), several pairs per wave (N < 64) or
 // ceil(N/64) wave passes per pair (N > 64).  Output: one visibility bit per sample.
 // ======================================================================================================
-template <bool COUNT>
+template <bool COUNT, bool FLAT>
 __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
                                                           const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                                            const DScene S, const DLights L, const int level, const int ctr_slot,
@@ -569,7 +644,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restr
         const bool sroot = valid && box_hit(root.bmin, sx, sy, sz, ddx, ddy, ddz);
         float t_unused = 0.f; int f_unused = -1;
         bool occ = false;
-        packet_walk<true, COUNT>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, sroot, sx, sy, sz, ddx, ddy, ddz, ddx, ddy, ddz, t_unused, f_unused, occ, c_box, c_ref);
+        walk<true, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, sroot, sx, sy, sz, ddx, ddy, ddz, ddx, ddy, ddz, t_unused, f_unused, occ, c_box, c_ref);
         const unsigned long long vm = __ballot(valid && !occ);
         if (N <= 64u) {
             if (s_in == 0u && slot < G && g < groups) {
@@ -605,6 +680,25 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restr
 // K3: Phong shading of lit hits + material dispatch + bounce-ray emission with wave-level compaction.
 // phongShade flyscene.cpp:822-859, getInterpolatedNormal :864-888, fresnel :890-910, traceRay dispatch :712-760.
 // ======================================================================================================
+// powf(cosphi, Ns) of phongShade (flyscene.cpp:852).  The CPU path calls glibc's powf (<= 0.52 ulp).  Here the power is
+// evaluated in DOUBLE and rounded to float once (= correctly rounded float except ~1e-7 of inputs): exponents that are
+// non-negative integers -- every shipped .mtl: 10, 324, 500, 225 -- by binary exponentiation (<= 20 DP multiplies, relative
+// error < 3e-15), anything else through pow(double, double).
+__device__ __forceinline__ float pow_shininess(float base, float expo) {
+    const float fl = floorf(expo);
+    if (fl == expo && expo >= 0.0f && expo <= 4096.0f) {
+        uint32_t n = static_cast<uint32_t>(expo);
+        double r = 1.0, b = static_cast<double>(base);
+        while (n != 0u) {
+            if (n & 1u) r = r * b;
+            b = b * b;
+            n >>= 1;
+        }
+        return static_cast<float>(r);
+    }
+    return static_cast<float>(pow(static_cast<double>(base), static_cast<double>(expo)));
+}
+
 __device__ __forceinline__ float fresnel_term(float ix, float iy, float iz, float nx, float ny, float nz, float ior) {
     float cosi = dot3(ix, iy, iz, nx, ny, nz);
     float etai = 1, etat = ior;
@@ -694,8 +788,7 @@ __global__ __launch_bounds__(256) void k_shade(const DScene S, const DLights L, 
                     float rx = ldx - two * nx, ry = ldy - two * ny, rz = ldz - two * nz;
                     normalize3(rx, ry, rz);
                     const float cosphi = smax(0.0f, dot3(ex, ey, ez, -1.0f * rx, -1.0f * ry, -1.0f * rz));
-                    // powf(cosphi, Ns): evaluated in double and rounded once (within 1 ulp of glibc's powf)
-                    const float pw = static_cast<float>(pow(static_cast<double>(cosphi), static_cast<double>(mat.shininess)));
+                    const float pw = pow_shininess(cosphi, mat.shininess);
                     cr = cr + ((L.color[0] * mat.kd[0]) * costheta + (L.color[0] * mat.ks[0]) * pw);
                     cg = cg + ((L.color[1] * mat.kd[1]) * costheta + (L.color[1] * mat.ks[1]) * pw);
                     cb = cb + ((L.color[2] * mat.kd[2]) * costheta + (L.color[2] * mat.ks[2]) * pw);
@@ -827,36 +920,51 @@ void launch_set_prof(hipStream_t, Control *) {}
 #endif
 
 // ------------------------------------------------------------------------------------------------------
-// residency: blocks per CU for each persistent kernel (fast variants), queried once per context
+// residency: blocks per CU for each persistent kernel (fast variants), queried once per scene
 // ------------------------------------------------------------------------------------------------------
-void query_occupancy(int *trace_primary, int *trace_rays, int *shadow, int *shade) {
+void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow, int *shade) {
     int n = 0;
-    *trace_primary = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<true, false>, RT_WAVES * 64, 0) == hipSuccess && n > 0) ? n : 4;
-    *trace_rays = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<false, false>, RT_WAVES * 64, 0) == hipSuccess && n > 0) ? n : 4;
-    *shadow = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shadow<false>, RT_WAVES * 64, 0) == hipSuccess && n > 0) ? n : 4;
-    *shade = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, 256, 0) == hipSuccess && n > 0) ? n : 2;
+    auto q = [&](auto kernel, int threads, int fallback) {
+        return (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) == hipSuccess && n > 0) ? n : fallback;
+    };
+    if (flat) {
+        *trace_primary = q(k_trace<true, false, true>, RT_WAVES * 64, 4);
+        *trace_rays = q(k_trace<false, false, true>, RT_WAVES * 64, 4);
+        *shadow = q(k_shadow<false, true>, RT_WAVES * 64, 4);
+    } else {
+        *trace_primary = q(k_trace<true, false, false>, RT_WAVES * 64, 4);
+        *trace_rays = q(k_trace<false, false, false>, RT_WAVES * 64, 4);
+        *shadow = q(k_shadow<false, false>, RT_WAVES * 64, 4);
+    }
+    *shade = q(k_shade, 256, 2);
 }
 
 // ------------------------------------------------------------------------------------------------------
 // host-callable launchers (keep <<<>>> syntax inside this translation unit)
 // ------------------------------------------------------------------------------------------------------
-void launch_trace(bool primary, bool count, int grid, hipStream_t st, const DScene &S, const DCam &cam, const DLights &L, const DFrame &F,
+#define RT_LAUNCH_TRACE(P, C, F) hipLaunchKernelGGL((k_trace<P, C, F>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, cam, L, Fr, level, slot, rays_in, items, ctl, rec, out_hit, out_t)
+void launch_trace(bool primary, bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DCam &cam, const DLights &L, const DFrame &Fr,
                   int level, int slot, const RayItem *rays_in, ShadeItem *items, Control *ctl, float4 *rec, int32_t *out_hit, float *out_t) {
     const dim3 g(grid), b(RT_WAVES * 64);
-    if (primary) {
-        if (count) hipLaunchKernelGGL((k_trace<true, true>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
-        else hipLaunchKernelGGL((k_trace<true, false>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
-    } else {
-        if (count) hipLaunchKernelGGL((k_trace<false, true>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
-        else hipLaunchKernelGGL((k_trace<false, false>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, cam, L, F, level, slot, rays_in, items, ctl, rec, out_hit, out_t);
+    const int sel = (primary ? 4 : 0) | (count ? 2 : 0) | (flat ? 1 : 0);
+    switch (sel) {
+        case 0: RT_LAUNCH_TRACE(false, false, false); break;
+        case 1: RT_LAUNCH_TRACE(false, false, true); break;
+        case 2: RT_LAUNCH_TRACE(false, true, false); break;
+        case 3: RT_LAUNCH_TRACE(false, true, true); break;
+        case 4: RT_LAUNCH_TRACE(true, false, false); break;
+        case 5: RT_LAUNCH_TRACE(true, false, true); break;
+        case 6: RT_LAUNCH_TRACE(true, true, false); break;
+        default: RT_LAUNCH_TRACE(true, true, true); break;
     }
 }
 
-void launch_shadow(bool count, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
+#define RT_LAUNCH_SHADOW(C, F) hipLaunchKernelGGL((k_shadow<C, F>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, L, level, slot, lslots, items, ctl, vis)
+void launch_shadow(bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
                    const ShadeItem *items, Control *ctl, unsigned long long *vis) {
     const dim3 g(grid), b(RT_WAVES * 64);
-    if (count) hipLaunchKernelGGL((k_shadow<true>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, L, level, slot, lslots, items, ctl, vis);
-    else hipLaunchKernelGGL((k_shadow<false>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, L, level, slot, lslots, items, ctl, vis);
+    if (count) { if (flat) RT_LAUNCH_SHADOW(true, true); else RT_LAUNCH_SHADOW(true, false); }
+    else { if (flat) RT_LAUNCH_SHADOW(false, true); else RT_LAUNCH_SHADOW(false, false); }
 }
 
 void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level, int slot, int lslots,
