@@ -321,25 +321,21 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                 // loads (ONE memory round trip per chunk instead of one per triangle), then read back as LDS
                 // broadcasts (all lanes the same address), software-pipelined one record ahead.
                 auto test_lane = [&](const TriRec &tr) {
-                    if (mine && !(ANY && (tr.flags & 1u))) {
-                        // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819
-                        const float dn = dot3(dx, dy, dz, tr.nx, tr.ny, tr.nz);
-                        if (dn != 0) {
-                            const float t = (tr.nA - dot3(ox, oy, oz, tr.nx, tr.ny, tr.nz)) / dn;
-                            const float v2x = (ox + t * dx) - tr.ax, v2y = (oy + t * dy) - tr.ay, v2z = (oz + t * dz) - tr.az;
-                            const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
-                            const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
-                            const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
-                            const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
-                            if ((u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f)) {
-                                if (ANY) {
-                                    if (t < 0.98f) occluded = true;
-                                } else if (t < best_t || (t == best_t && static_cast<int>(tr.face) < best_f)) {
-                                    best_t = t;
-                                    best_f = static_cast<int>(tr.face);
-                                }
-                            }
-                        }
+                    // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 (straight-line form, see flat_walk)
+                    const float dn = dot3(dx, dy, dz, tr.nx, tr.ny, tr.nz);
+                    const float t = (tr.nA - dot3(ox, oy, oz, tr.nx, tr.ny, tr.nz)) / dn;
+                    const float v2x = (ox + t * dx) - tr.ax, v2y = (oy + t * dy) - tr.ay, v2z = (oz + t * dz) - tr.az;
+                    const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
+                    const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
+                    const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
+                    const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
+                    const bool ok = mine && !(ANY && (tr.flags & 1u)) && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f);
+                    if (ANY) {
+                        occluded = occluded || (ok && t < 0.98f);
+                    } else {
+                        const bool better = ok && (t < best_t || (t == best_t && static_cast<int>(tr.face) < best_f));
+                        best_t = better ? t : best_t;
+                        best_f = better ? static_cast<int>(tr.face) : best_f;
                     }
                 };
                 if (cnt <= RT_SCALAR_LEAF_MAX) {
@@ -402,24 +398,24 @@ __device__ __forceinline__ void flat_walk(const rt_node &root, const TriRec *__r
     bool mine = in_root;
     for (uint32_t k = 0; k < cnt; ++k) {
         const TriRec tr = tri_load_uniform(T + k);
-        if (mine && !(ANY && (tr.flags & 1u))) {
-            // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819
+        {
+            // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 -- straight-line form: every lane evaluates the
+            // same operations (a zero d.n just produces inf/NaN that the final predicate rejects, exactly like the
+            // reference's early `return -72`), which removes the exec-mask juggling of nested branches.
             const float dn = dot3(dx, dy, dz, tr.nx, tr.ny, tr.nz);
-            if (dn != 0) {
-                const float t = (tr.nA - dot3(ox, oy, oz, tr.nx, tr.ny, tr.nz)) / dn;
-                const float v2x = (ox + t * dx) - tr.ax, v2y = (oy + t * dy) - tr.ay, v2z = (oz + t * dz) - tr.az;
-                const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
-                const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
-                const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
-                const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
-                if ((u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f)) {
-                    if (ANY) {
-                        if (t < 0.98f) occluded = true;
-                    } else if (t < best_t || (t == best_t && static_cast<int>(tr.face) < best_f)) {
-                        best_t = t;
-                        best_f = static_cast<int>(tr.face);
-                    }
-                }
+            const float t = (tr.nA - dot3(ox, oy, oz, tr.nx, tr.ny, tr.nz)) / dn;
+            const float v2x = (ox + t * dx) - tr.ax, v2y = (oy + t * dy) - tr.ay, v2z = (oz + t * dz) - tr.az;
+            const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
+            const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
+            const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
+            const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
+            const bool ok = mine && !(ANY && (tr.flags & 1u)) && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f);
+            if (ANY) {
+                occluded = occluded || (ok && t < 0.98f);
+            } else {
+                const bool better = ok && (t < best_t || (t == best_t && static_cast<int>(tr.face) < best_f));
+                best_t = better ? t : best_t;
+                best_f = better ? static_cast<int>(tr.face) : best_f;
             }
         }
         if (ANY && !COUNT && (k & 7u) == 7u) {
