@@ -143,6 +143,41 @@ def main():
     render(_p(0), brk)
     torch.cuda.synchronize(dev)
 
+    # ---- extra (untimed for `value`): the same K frames replayed from ONE captured hipGraph, camera yaw stepping
+    # 2*pi/120 per frame (BASELINE cfg5's animation path); reported as graph_replay_ms_per_frame
+    graph_ms = None
+    graph_same_ms = None
+    try:
+        g = pkg.FrameGraph(ctx, L, _p(0), out_rgb.data_ptr(), out_u8.data_ptr())
+        cams = [pkg.default_camera(W, H, float(np.float32(2.0 * np.pi * f / 120.0))) for f in range(args.steps)]
+        g.launch(cams[0], stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        tg0 = time.perf_counter()
+        for f in range(args.steps):
+            g.launch(cams[f], stream.cuda_stream)
+            if world > 1:
+                bufs = [torch.empty_like(out_u8) for _ in range(world)] if rank == 0 else None
+                dist.gather(out_u8, gather_list=bufs, dst=0)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        graph_ms = (time.perf_counter() - tg0) / args.steps * 1e3
+        tg0 = time.perf_counter()
+        for f in range(args.steps):               # same camera as the timed region: the launch-overhead comparison
+            g.launch(cam, stream.cuda_stream)
+            if world > 1:
+                bufs = [torch.empty_like(out_u8) for _ in range(world)] if rank == 0 else None
+                dist.gather(out_u8, gather_list=bufs, dst=0)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        graph_same_ms = (time.perf_counter() - tg0) / args.steps * 1e3
+        g.close()
+    except Exception as e:            # the graph path is an extra; never let it take the bench line down
+        graph_ms = f"failed: {e}"
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -184,6 +219,8 @@ def main():
                    "width": W, "height": H, "max_depth": D, "samples": G * G, "scene": scene_file,
                    "parallelism": f"rows{world}"},
         "rays_per_frame": rays_frame,
+        "graph_replay_ms_per_frame_120_frame_yaw_path": (round(graph_ms, 4) if isinstance(graph_ms, float) else graph_ms),
+        "graph_replay_ms_per_frame_same_camera": (round(graph_same_ms, 4) if isinstance(graph_same_ms, float) else graph_same_ms),
         "rays": {"primary": tot[6], "centre": tot[7], "sample": tot[5], "bounce": tot[8], "culled_pixels": tot[9]},
         "roofline": roofline,
     }

@@ -146,6 +146,20 @@ rt_status rt_render_device(rt_ctx *ctx, const rt_camera *cam, const rt_lights *l
  * with collect_stats == 2 since the last call, plus the ray counters of the last frame.  Synchronises the stream.  */
 rt_status rt_timing_collect(rt_ctx *ctx, rt_stats *out);
 
+/* ---- captured frames (hipGraph) -------------------------------------------------------------------------------
+ * The launch sequence of a frame has no host round trip, so it is captured once into a hipGraph and replayed per frame
+ * (animation paths: BASELINE cfg5).  Lights, frame size, shard and output buffers are frozen at capture; the camera is
+ * read from device memory and may change on every launch.  No reference counterpart (the reference re-runs
+ * raytraceScene per key press, main.cpp:69-70).                                                                    */
+typedef struct rt_graph rt_graph;
+rt_status rt_graph_create(rt_ctx *ctx, const rt_lights *lights, const rt_params *p, float *d_out_rgb, uint8_t *d_out_u8,
+                          rt_graph **out);
+/* asynchronous: uploads `cam`, then replays the captured frame on `stream` (NULL = the context's stream)             */
+rt_status rt_graph_launch(rt_graph *g, const rt_camera *cam, void *stream);
+/* synchronises and returns the ray counters of the last replayed frame                                             */
+rt_status rt_graph_stats(rt_graph *g, rt_stats *out);
+void      rt_graph_destroy(rt_graph *g);
+
 /* number of rows rt_render produces for p */
 int32_t rt_local_rows(const rt_params *p);
 

@@ -3,6 +3,6 @@
 Only what the path needs lives here: csrc/ (HIP kernels + C ABI + GL-free host scene code), the ctypes binding
 (capi), the Python mirror of the reference's Flyscene interface (flyscene) and the row-shard helpers (shard).
 """
-from . import capi, shard  # noqa: F401
+from . import capi, hipmem, shard  # noqa: F401
 from .capi import load_library  # noqa: F401
-from .flyscene import Context, Flyscene, HostScene, default_camera, make_lights, make_params  # noqa: F401
+from .flyscene import Context, Flyscene, FrameGraph, HostScene, default_camera, make_lights, make_params  # noqa: F401

@@ -80,6 +80,10 @@ _SIGNATURES = [
     ("rt_render_device", C.c_int, [C.c_void_p, _P(rt_camera), _P(rt_lights), _P(rt_params), C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, _P(rt_stats)]),
     ("rt_timing_collect", C.c_int, [C.c_void_p, _P(rt_stats)]),
+    ("rt_graph_create", C.c_int, [C.c_void_p, _P(rt_lights), _P(rt_params), C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
+    ("rt_graph_launch", C.c_int, [C.c_void_p, _P(rt_camera), C.c_void_p]),
+    ("rt_graph_stats", C.c_int, [C.c_void_p, _P(rt_stats)]),
+    ("rt_graph_destroy", None, [C.c_void_p]),
     ("rt_local_rows", C.c_int32, [_P(rt_params)]),
     ("rt_trace_rays", C.c_int, [C.c_void_p, _P(rt_lights), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),

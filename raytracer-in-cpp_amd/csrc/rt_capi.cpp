@@ -16,7 +16,7 @@
 #include "rt_mi355x.h"
 
 namespace rtamd {
-void launch_trace(bool primary, bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DCam &cam, const DLights &L, const DFrame &F,
+void launch_trace(bool primary, bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DCam *camp, const DLights &L, const DFrame &F,
                   int level, int slot, const RayItem *rays_in, ShadeItem *items, Control *ctl, float4 *rec, int32_t *out_hit, float *out_t);
 void launch_shadow(bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
                    const ShadeItem *items, Control *ctl, unsigned long long *vis);
@@ -59,6 +59,10 @@ struct rt_ctx {
     float4 *d_rec = nullptr;
     float *d_fres = nullptr;
     Control *d_ctl = nullptr;
+    DCam *d_cam = nullptr;            // camera of the frame in flight (device memory: graph-replayable)
+    DCam *h_cam_ring = nullptr;       // pinned staging ring for asynchronous camera uploads
+    uint32_t cam_slot = 0;
+    uint64_t frame_generation = 0;    // bumped whenever the frame buffers are reallocated (invalidates captured graphs)
     float *d_rgb = nullptr;      // staging for rt_render (host output)
     int32_t *d_hit = nullptr;
     float *d_t = nullptr;
@@ -71,6 +75,7 @@ struct rt_ctx {
     DFrame pending_frame{};
 };
 
+static constexpr uint32_t kCamRing = 512;   // camera uploads that may be queued before one is consumed
 static const char *k_no_ctx = "rt_mi355x: null context";
 
 #define HIPCHK(ctx, call)                                                                                      \
@@ -105,7 +110,13 @@ extern "C" rt_status rt_create(rt_ctx **out, int device) {
         if (m > 0 && m <= 64) c->grid_mult = m;
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RT_ERR_HIP; }
-    if (hipMalloc(reinterpret_cast<void **>(&c->d_ctl), sizeof(Control)) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return RT_ERR_HIP; }
+    if (hipMalloc(reinterpret_cast<void **>(&c->d_ctl), sizeof(Control)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->d_cam), sizeof(DCam)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&c->h_cam_ring), sizeof(DCam) * kCamRing, hipHostMallocDefault) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return RT_ERR_HIP;
+    }
     *out = c;
     return RT_OK;
 }
@@ -137,6 +148,8 @@ extern "C" void rt_destroy(rt_ctx *c) {
     if (c->d_hit) (void)hipFree(c->d_hit);
     if (c->d_t) (void)hipFree(c->d_t);
     if (c->d_ctl) (void)hipFree(c->d_ctl);
+    if (c->d_cam) (void)hipFree(c->d_cam);
+    if (c->h_cam_ring) (void)hipHostFree(c->h_cam_ring);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -410,6 +423,7 @@ static rt_status ensure_frame(rt_ctx *c, size_t npix, int levels, size_t vis_wor
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_rec), np * static_cast<size_t>(lv) * sizeof(float4)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_fres), np * static_cast<size_t>(lv) * sizeof(float)));
         c->cap_pix = np; c->cap_levels = lv; c->cap_vis = vw;
+        ++c->frame_generation;
     }
     return RT_OK;
 }
@@ -437,8 +451,11 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
     launch_set_prof(st, c->d_ctl);   // no-op unless built with -DRT_PROFILE
     if (!primary) HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->d_ctl->n_rays[0]), static_cast<int>(n_input_rays), 1, st));
     size_t ev = c->ev_base;
-    DCam cam0{};
-    if (cam) cam0 = *cam;
+    if (cam) {   // asynchronous camera upload through the pinned ring (skipped when replaying a captured graph)
+        DCam *slot = &c->h_cam_ring[c->cam_slot++ % kCamRing];
+        *slot = *cam;
+        HIPCHK(c, hipMemcpyAsync(c->d_cam, slot, sizeof(DCam), hipMemcpyHostToDevice, st));
+    }
     // timed == 1: an event between every pair of launches (per-kernel breakdown; adds ~4 us per boundary)
     // timed == 2: lean set for timed loops -- frame start, around each k_shadow launch, frame end
     if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
@@ -446,7 +463,7 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
         float4 *rec_l = c->d_rec + static_cast<size_t>(level) * F.npix;
         float *fres_l = c->d_fres + static_cast<size_t>(level) * F.npix;
         const bool prim = primary && level == 0;
-        launch_trace(prim, count, c->flat, c->cus * (prim ? c->occ_trace_primary : c->occ_trace_rays), st, c->S, cam0, L, F, level, 3 * level, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
+        launch_trace(prim, count, c->flat, c->cus * (prim ? c->occ_trace_primary : c->occ_trace_rays), st, c->S, c->d_cam, L, F, level, 3 * level, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
                      level == 0 ? d_hit : nullptr, level == 0 ? d_t : nullptr);
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
         launch_shadow(count, c->flat, c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, c->d_items, c->d_ctl, c->d_vis);
@@ -577,6 +594,87 @@ extern "C" rt_status rt_render_device(rt_ctx *c, const rt_camera *cam, const rt_
         stats->box_tests = bt; stats->leaf_tri_refs = lr; stats->box_tests_shadow = bts; stats->leaf_tri_refs_shadow = lrs;
     }
     return RT_OK;
+}
+
+struct rt_graph {
+    rt_ctx *ctx = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    DFrame F{};
+    uint64_t generation = 0;
+    hipStream_t last_stream = nullptr;
+};
+
+extern "C" rt_status rt_graph_create(rt_ctx *c, const rt_lights *lights, const rt_params *p, float *d_out_rgb, uint8_t *d_out_u8,
+                                     rt_graph **out) {
+    if (!c || !out) return RT_ERR_INVALID;
+    *out = nullptr;
+    if (!c->has_scene) { c->err = "rt_graph_create before rt_upload_scene"; return RT_ERR_NO_SCENE; }
+    if (!d_out_rgb && !d_out_u8) { c->err = "rt_graph_create: no output buffer"; return RT_ERR_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    DLights L;
+    rt_status s = check_lights(c, lights, &L);
+    if (s != RT_OK) return s;
+    DFrame F;
+    if ((s = make_frame(c, p, &F)) != RT_OK) return s;
+    if (F.npix == 0) { c->err = "rt_graph_create: empty shard"; return RT_ERR_INVALID; }
+    // every allocation happens BEFORE the capture
+    const size_t P = (static_cast<size_t>(L.n_samples) + 63) / 64;
+    if ((s = ensure_frame(c, F.npix, F.max_depth + 1, static_cast<size_t>(F.npix) * L.n_lights * P)) != RT_OK) return s;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rt_graph *g = new rt_graph();
+    g->ctx = c; g->F = F; g->generation = c->frame_generation;
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { delete g; c->err = "hipStreamBeginCapture failed"; return RT_ERR_HIP; }
+    s = run_frame(c, c->stream, nullptr, L, F, true, false, d_out_rgb, d_out_u8, nullptr, nullptr, 0, 0);
+    const hipError_t e = hipStreamEndCapture(c->stream, &g->graph);
+    if (s != RT_OK || e != hipSuccess || !g->graph) {
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        delete g;
+        if (s == RT_OK) { c->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); s = RT_ERR_HIP; }
+        return s;
+    }
+    if (hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGraphDestroy(g->graph);
+        delete g;
+        c->err = "hipGraphInstantiate failed";
+        return RT_ERR_HIP;
+    }
+    *out = g;
+    return RT_OK;
+}
+
+extern "C" rt_status rt_graph_launch(rt_graph *g, const rt_camera *cam, void *stream) {
+    if (!g || !cam) return RT_ERR_INVALID;
+    rt_ctx *c = g->ctx;
+    if (g->generation != c->frame_generation) { c->err = "rt_graph_launch: the frame buffers were reallocated after capture; re-create the graph"; return RT_ERR_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    DCam dc;
+    make_cam(cam, &dc);
+    DCam *slot = &c->h_cam_ring[c->cam_slot++ % kCamRing];
+    *slot = dc;
+    HIPCHK(c, hipMemcpyAsync(c->d_cam, slot, sizeof(DCam), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipGraphLaunch(g->exec, st));
+    g->last_stream = st;
+    return RT_OK;
+}
+
+extern "C" rt_status rt_graph_stats(rt_graph *g, rt_stats *out) {
+    if (!g || !out) return RT_ERR_INVALID;
+    rt_ctx *c = g->ctx;
+    std::memset(out, 0, sizeof *out);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int levels_run = c->reflective ? g->F.max_depth + 1 : 1;
+    return fill_stats(c, g->last_stream ? g->last_stream : c->stream, g->F, levels_run, false, out, false);
+}
+
+extern "C" void rt_graph_destroy(rt_graph *g) {
+    if (!g) return;
+    (void)hipSetDevice(g->ctx->device);
+    if (g->last_stream) (void)hipStreamSynchronize(g->last_stream);
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
 }
 
 extern "C" rt_status rt_timing_collect(rt_ctx *c, rt_stats *out) {

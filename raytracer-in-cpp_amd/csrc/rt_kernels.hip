@@ -462,7 +462,7 @@ __device__ __forceinline__ void light_sample(const DLights &L, const float px, c
 template <bool PRIMARY, bool COUNT, bool FLAT>
 __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
                                                           const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
-                                                          const DScene S, const DCam cam, const DLights L, const DFrame F,
+                                                          const DScene S, const DCam *__restrict__ camp, const DLights L, const DFrame F,
                                                           const int level, const int ctr_slot,
                                                           const RayItem *__restrict__ rays_in, ShadeItem *__restrict__ items,
                                                           Control *__restrict__ ctl, float4 *__restrict__ rec,
@@ -475,6 +475,9 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
     const uint32_t n_in = PRIMARY ? 0u : ctl->n_rays[level];
     const uint32_t ntiles = PRIMARY ? static_cast<uint32_t>(F.tiles_x) * static_cast<uint32_t>(F.tiles_y) : (n_in + 63u) / 64u;
     const rt_node root = nodes[0];
+    // the camera lives in device memory so that a captured hipGraph of the frame can be replayed with a new camera
+    DCam cam;
+    if (PRIMARY) cam = *camp;
 
     uint32_t c_rays = 0, c_cull = 0, c_centre = 0, c_box = 0, c_ref = 0;
     ShardedQueue q;
@@ -938,8 +941,8 @@ void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow
 // ------------------------------------------------------------------------------------------------------
 // host-callable launchers (keep <<<>>> syntax inside this translation unit)
 // ------------------------------------------------------------------------------------------------------
-#define RT_LAUNCH_TRACE(P, C, F) hipLaunchKernelGGL((k_trace<P, C, F>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, cam, L, Fr, level, slot, rays_in, items, ctl, rec, out_hit, out_t)
-void launch_trace(bool primary, bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DCam &cam, const DLights &L, const DFrame &Fr,
+#define RT_LAUNCH_TRACE(P, C, F) hipLaunchKernelGGL((k_trace<P, C, F>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, camp, L, Fr, level, slot, rays_in, items, ctl, rec, out_hit, out_t)
+void launch_trace(bool primary, bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DCam *camp, const DLights &L, const DFrame &Fr,
                   int level, int slot, const RayItem *rays_in, ShadeItem *items, Control *ctl, float4 *rec, int32_t *out_hit, float *out_t) {
     const dim3 g(grid), b(RT_WAVES * 64);
     const int sel = (primary ? 4 : 0) | (count ? 2 : 0) | (flat ? 1 : 0);

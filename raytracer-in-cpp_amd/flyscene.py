@@ -233,3 +233,36 @@ class Flyscene:
     def addLight(self):
         if len(self.lights) < capi.RT_MAX_LIGHTS:
             self.lights.append(tuple(float(x) for x in self.camera.center))
+
+
+class FrameGraph:
+    """rt_graph: one frame's launch sequence captured into a hipGraph, replayed with a new camera per frame.
+    Output buffers are caller-owned device memory (e.g. torch tensors); this class only keeps their addresses."""
+
+    def __init__(self, ctx, lights, params, d_rgb_ptr=None, d_u8_ptr=None):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.handle = C.c_void_p()
+        st = self.lib.rt_graph_create(ctx.handle, C.byref(lights), C.byref(params),
+                                      C.c_void_p(d_rgb_ptr) if d_rgb_ptr else None,
+                                      C.c_void_p(d_u8_ptr) if d_u8_ptr else None, C.byref(self.handle))
+        capi.check(self.lib, ctx.handle, st, "rt_graph_create")
+
+    def launch(self, camera, stream_ptr=None):
+        st = self.lib.rt_graph_launch(self.handle, C.byref(camera), C.c_void_p(stream_ptr) if stream_ptr else None)
+        capi.check(self.lib, self.ctx.handle, st, "rt_graph_launch")
+
+    def stats(self):
+        out = capi.rt_stats()
+        capi.check(self.lib, self.ctx.handle, self.lib.rt_graph_stats(self.handle, C.byref(out)), "rt_graph_stats")
+        return out
+
+    def close(self):
+        if self.handle:
+            self.lib.rt_graph_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

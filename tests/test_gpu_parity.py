@@ -268,3 +268,43 @@ def test_chunk_culling_is_exact(rt, oracle, scenes):
         assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), cap
         assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32)), cap
         assert np.array_equal(a[4].view(np.uint32), b[4].view(np.uint32)), cap
+
+
+def test_hipgraph_animation_replay(rt, oracle, scenes):
+    """BASELINE cfg5 in miniature: the frame is captured ONCE into a hipGraph and replayed with a new fly-camera yaw per
+    frame (device-resident camera).  Every replayed frame is bit-identical to the eagerly launched frame, a few are
+    checked against the oracle, and the ray counters of a replay equal the eager ones."""
+    w, h, frames = 160, 90, 12
+    for name in ("dodgeColorTest.obj", "cube.obj"):
+        path = os.path.join(scenes, name)
+        fs = rt.Flyscene(scene_path=path)
+        fs.initialize(w, h, True, False)
+        fs.usteps = fs.vsteps = 4
+        fs.max_depth = 4
+        L = fs._lights()
+        p = rt.make_params(w, h, 4)
+        out = rt.hipmem.DeviceBuffer(h * w * 3 * 4)
+        out8 = rt.hipmem.DeviceBuffer(h * w * 3)
+        g = rt.FrameGraph(fs.ctx, L, p, out.address, out8.address)
+        osc = oracle.load_scene(path)
+        for f in range(frames):
+            yaw = float(np.float32(2.0 * np.pi * f / frames))
+            cam = rt.default_camera(w, h, yaw)
+            g.launch(cam)
+            st = g.stats()                      # synchronises
+            got = out.to_numpy(np.float32, (h, w, 3))
+            got8 = out8.to_numpy(np.uint8, (h, w, 3))
+            fs.camera = cam
+            eager = fs.raytraceScene(w, h, write_ppm=False)
+            assert np.array_equal(got.view(np.uint32), eager.view(np.uint32)), (name, f)
+            assert st.total_rays() == fs.stats.total_rays()
+            assert np.array_equal(got8, np.clip(oracle.quantise(got), 0, 255).astype(np.uint8))
+            if f in (0, 5):
+                ref, _, _ = osc.render(oracle.camera(w, h, yaw), oracle.lights(area=True, usteps=4, vsteps=4), w, h, max_depth=4, threads=8)
+                assert np.abs(got - ref).max() <= RGB_TOL
+                assert (oracle.quantise(got) != oracle.quantise(ref)).sum() <= 1
+        g.close()
+        out.free()
+        out8.free()
+        osc.close()
+        fs.ctx.close()
