@@ -29,7 +29,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scene", default="cube", choices=["cube", "dodge"])
+    ap.add_argument("--scene", default="cube", choices=["cube", "dodge", "wavy"],
+                    help="wavy = the ~1M-triangle synthetic mesh of BASELINE cfg4 (use with --width 3840 --height 2160 --grid 16 --depth 8)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--grid", type=int, default=8, help="area-light grid side (8 -> 64 samples)")
@@ -62,8 +63,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    scene_file = {"cube": "cube.obj", "dodge": "dodgeColorTest.obj"}[args.scene]
-    scene_path = os.path.join(ROOT, "tests", "golden", "scenes", scene_file)
+    if args.scene == "wavy":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import scenes_gen
+        import tempfile
+        scene_file = "wavy708.obj (synthetic 708x708 displaced grid + floor, 1,002,530 triangles)"
+        scene_path = scenes_gen.wavy_grid(os.path.join(tempfile.gettempdir(), f"rt_wavy_{os.getpid()}"), n=708)
+    else:
+        scene_file = {"cube": "cube.obj", "dodge": "dodgeColorTest.obj"}[args.scene]
+        scene_path = os.path.join(ROOT, "tests", "golden", "scenes", scene_file)
     W, H, G, D, S = args.width, args.height, args.grid, args.depth, args.stripe
 
     hs = pkg.HostScene(scene_path, 1000, 15)
@@ -196,9 +204,21 @@ def main():
     achieved = alg_per_launch / (avg_ms_shadow * 1e-3) / 1e9 if avg_ms_shadow > 0 else 0.0
     trace_alg = BOX_BYTES * (cnt.box_tests - cnt.box_tests_shadow) + TRI_REF_BYTES * (cnt.leaf_tri_refs - cnt.leaf_tri_refs_shadow)
     trace_gbs = trace_alg / (brk.ms_trace * 1e-3) / 1e9 if brk.ms_trace > 0 else 0.0
+    # HBM traffic of the dominant kernel from the PMC counters (separate rocprofv3 --pmc passes, profiles/traffic.json);
+    # only quoted when the committed measurement is for this very workload
+    traffic = None
+    traffic_note = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        ent = tj.get(args.scene)
+        if ent and ent["config"] == f"{W}x{H} depth {D} {G * G} samples" and world == 1:
+            traffic = ent["hbm_bytes_per_launch"]
+            traffic_note = ent["how"]
+    except Exception:
+        pass
     roofline = {
         "bound": "hbm", "kernel": "k_shadow", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
         "algorithmic_bytes_per_launch": int(alg_per_launch), "avg_launch_ms": round(avg_ms_shadow, 5),
         "launches_per_frame": launches_per_frame,
         "note": "algorithmic bytes = 24 B x box tests + 52 B x leaf triangle refs in reference semantics (no early-out); "
@@ -214,7 +234,7 @@ def main():
         "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{W}x{H} depth {D} {G * G}-sample area light, {scene_file} (default resources/models scene), "
+        "config": {"workload": f"{W}x{H} depth {D} {G * G}-sample area light, {scene_file}, "
                                f"1 light, row stripes of {S} over {world} GPU(s)",
                    "width": W, "height": H, "max_depth": D, "samples": G * G, "scene": scene_file,
                    "parallelism": f"rows{world}"},

@@ -42,9 +42,10 @@ static_assert(sizeof(TriRec) == 80, "TriRec must be 80 bytes");
 // in the kernel: |d.n| > tau |d|).
 struct alignas(16) ChunkBound {
     float lo[3], hi[3];      // AABB of the chunk's triangles, inflated
-    float ax, ay, az;        // unused (reserved)
+    float ax, ay, az;        // normal-cone axis (valid when pad0 < 1.5)
     float sin_guard;         // 0: chunk may be culled; 2: never (ill-conditioned / degenerate / non-finite triangle inside)
-    float pad0, pad1;
+    float pad0;              // sin(cone half-angle + guard angle), or 2 when the chunk has no usable cone
+    float pad1;
 };
 static_assert(sizeof(ChunkBound) == 48, "ChunkBound must be 48 bytes");
 

@@ -243,7 +243,8 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                 // per-ray quantities of the conservative chunk test (approximate arithmetic is fine: they only ever SKIP
                 // work); computed per leaf visit so that scenes that never take this mode (the cube) pay nothing
                 const float q_len = dx * dx + dy * dy + dz * dz;
-                const float guard_len = 0.002f * 1.001f * sqrtf(q_len);           // tau * |d|, tau = 0.002
+                const float d_len = sqrtf(q_len);
+                const float guard_len = 0.002f * 1.001f * d_len;                  // tau * |d|, tau = 0.002
                 const float idx_ = fabsf(dx) > 1e-30f ? 1.0f / dx : copysignf(1e30f, dx);   // never inf: no inf*0 NaNs
                 const float idy_ = fabsf(dy) > 1e-30f ? 1.0f / dy : copysignf(1e30f, dy);
                 const float idz_ = fabsf(dz) > 1e-30f ? 1.0f / dz : copysignf(1e30f, dz);
@@ -254,8 +255,9 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                     const bool has = static_cast<uint32_t>(lane) < n && !(ANY && (tr.flags & 1u));
                     const uint32_t nx = c0 + 64u + static_cast<uint32_t>(lane);
                     const TriRec nxt = T[nx < cnt ? nx : 0u];                      // prefetch (uniformly skipped work is cheap)
-                    // conservative chunk test, step 1 (lanes = rays): which live rays' LINES miss the inflated chunk box
-                    unsigned long long todo = live, boxmiss = 0ull;
+                    // conservative chunk test, step 1 (lanes = rays): which live rays' LINES miss the inflated chunk box, and
+                    // which of those are also outside the chunk's normal cone band (then no plane of the chunk is near-parallel)
+                    unsigned long long todo = live, guard_rays = 0ull;
                     {
                         const ChunkBound cb = cbounds[c0 >> 6];
                         if (cb.sin_guard < 1.5f) {
@@ -264,49 +266,74 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                             const float t0z = (cb.lo[2] - slab_pad - oz) * idz_, t1z = (cb.hi[2] + slab_pad - oz) * idz_;
                             const float tin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
                             const float tout = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-                            boxmiss = __ballot(tin > tout) & live;
+                            const bool miss = tin > tout;
+                            const bool cone_safe = fabsf(dx * cb.ax + dy * cb.ay + dz * cb.az) > cb.pad0 * d_len;
+                            const unsigned long long boxmiss = __ballot(miss) & live;
+                            const unsigned long long culled = __ballot(miss && cone_safe) & live;
+                            todo = live & ~culled;
+                            guard_rays = boxmiss & ~culled;          // must pass the per-triangle guard to be skipped
+                            RT_PROF_ADD(lane, 14, __popcll(culled));
                         }
                     }
+                    // step 2 (lanes = triangles), rare: rays whose line misses the box but that may be near-parallel to some
+                    // plane of the chunk: skip only if |d.n| > tau |d| holds for EVERY triangle (near-parallel pairs make the
+                    // reference's t, hence its hit point, arbitrarily wrong and are always tested)
+                    while (guard_rays != 0ull) {
+                        const int r = static_cast<int>(__builtin_ctzll(guard_rays));
+                        guard_rays &= guard_rays - 1ull;
+                        const float dn = dot3(lane_f(dx, r), lane_f(dy, r), lane_f(dz, r), tr.nx, tr.ny, tr.nz);
+                        if (__ballot(has && !(fabsf(dn) > lane_f(guard_len, r))) == 0ull) { todo &= ~(1ull << r); RT_PROF_ADD(lane, 12, 1); }
+                        else RT_PROF_ADD(lane, 13, 1);
+                    }
+                    // step 3 (lanes = triangles): full test of the surviving rays, two rays per step for ILP (two independent
+                    // division chains in flight)
                     while (todo != 0ull) {
-                        const int r = static_cast<int>(__builtin_ctzll(todo));
+                        const int r0 = static_cast<int>(__builtin_ctzll(todo));
                         todo &= todo - 1ull;
-                        const float rdx = lane_f(dx, r), rdy = lane_f(dy, r), rdz = lane_f(dz, r);
+                        const bool two = todo != 0ull;
+                        const int r1 = two ? static_cast<int>(__builtin_ctzll(todo)) : r0;
+                        if (two) todo &= todo - 1ull;
+                        RT_PROF_ADD(lane, 2, two ? 2 : 1); RT_PROF_ADD(lane, 3, (two ? 2 : 1) * __popcll(__ballot(has)));
                         // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 (same operations as the ray-lane form)
-                        const float dn = dot3(rdx, rdy, rdz, tr.nx, tr.ny, tr.nz);
-                        if ((boxmiss >> r) & 1ull) {
-                            // step 2 (lanes = triangles): the skip is only sound when the ray is not within the guard angle
-                            // of being parallel to ANY plane of the chunk (|d.n| > tau |d|, unit normals): near-parallel
-                            // pairs make the reference's t, hence its hit point, arbitrarily wrong and are always tested.
-                            if (__ballot(has && !(fabsf(dn) > lane_f(guard_len, r))) == 0ull) { RT_PROF_ADD(lane, 12, 1); continue; }
-                            RT_PROF_ADD(lane, 13, 1);
+                        float tq[2]; bool inq[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int r = q == 0 ? r0 : r1;
+                            const float rdx = lane_f(dx, r), rdy = lane_f(dy, r), rdz = lane_f(dz, r);
+                            const float rox = lane_f(ox, r), roy = lane_f(oy, r), roz = lane_f(oz, r);
+                            const float dn = dot3(rdx, rdy, rdz, tr.nx, tr.ny, tr.nz);
+                            const float t = (tr.nA - dot3(rox, roy, roz, tr.nx, tr.ny, tr.nz)) / dn;
+                            const float v2x = (rox + t * rdx) - tr.ax, v2y = (roy + t * rdy) - tr.ay, v2z = (roz + t * rdz) - tr.az;
+                            const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
+                            const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
+                            const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
+                            const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
+                            tq[q] = t;
+                            inq[q] = has && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f);
                         }
-                        const float rox = lane_f(ox, r), roy = lane_f(oy, r), roz = lane_f(oz, r);
-                        const float t = (tr.nA - dot3(rox, roy, roz, tr.nx, tr.ny, tr.nz)) / dn;
-                        const float v2x = (rox + t * rdx) - tr.ax, v2y = (roy + t * rdy) - tr.ay, v2z = (roz + t * rdz) - tr.az;
-                        const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
-                        const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
-                        const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
-                        const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
-                        const bool inside = has && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f);
-                        RT_PROF_ADD(lane, 2, 1); RT_PROF_ADD(lane, 3, __popcll(__ballot(has)));
-                        if (ANY) {
-                            if (__ballot(inside && t < 0.98f) != 0ull) {
-                                occ_new |= 1ull << r;
-                                if (!COUNT) live &= ~(1ull << r);
-                            }
-                        } else {
-                            unsigned long long hm = __ballot(inside);
-                            if (hm != 0ull) {
-                                float bt = lane_f(best_t, r);
-                                int bf = __builtin_amdgcn_readlane(best_f, r);
-                                do {
-                                    const int l = static_cast<int>(__builtin_ctzll(hm));
-                                    hm &= hm - 1ull;
-                                    const float tl = lane_f(t, l);
-                                    const int fl = __builtin_amdgcn_readlane(static_cast<int>(tr.face), l);
-                                    if (tl < bt || (tl == bt && fl < bf)) { bt = tl; bf = fl; }
-                                } while (hm != 0ull);
-                                if (lane == r) { best_t = bt; best_f = bf; }
+                        if (!two) inq[1] = false;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int r = q == 0 ? r0 : r1;
+                            if (ANY) {
+                                if (__ballot(inq[q] && tq[q] < 0.98f) != 0ull) {
+                                    occ_new |= 1ull << r;
+                                    if (!COUNT) live &= ~(1ull << r);
+                                }
+                            } else {
+                                unsigned long long hm = __ballot(inq[q]);
+                                if (hm != 0ull) {
+                                    float bt = lane_f(best_t, r);
+                                    int bf = __builtin_amdgcn_readlane(best_f, r);
+                                    do {
+                                        const int l = static_cast<int>(__builtin_ctzll(hm));
+                                        hm &= hm - 1ull;
+                                        const float tl = lane_f(tq[q], l);
+                                        const int fl = __builtin_amdgcn_readlane(static_cast<int>(tr.face), l);
+                                        if (tl < bt || (tl == bt && fl < bf)) { bt = tl; bf = fl; }
+                                    } while (hm != 0ull);
+                                    if (lane == r) { best_t = bt; best_f = bf; }
+                                }
                             }
                         }
                     }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # quick GPU iteration loop: a few parity tests + bench on both scenes (used through gpurun)
 mkdir -p gpurun_out
-timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "cube_256 or dodge_matches or counters or shards or material or culling or deep_tree" > gpurun_out/pytest_quick.log 2>&1
+timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "cube_256 or dodge_matches or counters or shards or material or culling or deep_tree or hipgraph" > gpurun_out/pytest_quick.log 2>&1
 rc=$?; echo "pytest exit $rc"; tail -3 gpurun_out/pytest_quick.log
 if [ $rc -ne 0 ]; then echo "parity failed: not running the bench"; exit 1; fi
 for sc in cube dodge; do

@@ -1,13 +1,20 @@
-# diagnostic: render one frame with the RT_PROFILE build and print executed-work counters per kernel split
+# diagnostic: render one frame with the RT_PROFILE build and print executed-work counters
 import ctypes as C, os, sys
 os.environ["RT_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "raytracer-in-cpp_amd", "lib", "librt_mi355x_prof.so")
+sys.path.insert(0, "tests")
 import rtpkg
 pkg = rtpkg.load()
 scene = sys.argv[1] if len(sys.argv) > 1 else "dodgeColorTest.obj"
-fs = pkg.Flyscene(scene_path=os.path.join("tests/golden/scenes", scene))
-fs.initialize(1920, 1080, True, False)
-fs.usteps = fs.vsteps = 8
-fs.max_depth = 4
-fs.raytraceScene(1920, 1080, write_ppm=False)
+w, h, u, d = (int(x) for x in (sys.argv[2:6] if len(sys.argv) > 5 else (1920, 1080, 8, 4)))
+if scene == "wavy":
+    import scenes_gen
+    path = scenes_gen.wavy_grid("/tmp/rt_wavy_prof", n=708)
+else:
+    path = os.path.join("tests/golden/scenes", scene)
+fs = pkg.Flyscene(scene_path=path)
+fs.initialize(w, h, True, False)
+fs.usteps = fs.vsteps = u
+fs.max_depth = d
+fs.raytraceScene(w, h, write_ppm=False)
 st = fs.stats
-print("rays", st.total_rays(), "ms", st.ms_trace, st.ms_shadow, st.ms_shade)
+print("rays", st.total_rays(), "items", st.shaded_hits, "ms", st.ms_trace, st.ms_shadow, st.ms_shade)
