@@ -78,6 +78,30 @@ __device__ __forceinline__ bool box_hit(const float *__restrict__ b, float ox, f
 //     each head is hit from one XCD's L2 -- and the interleaving keeps all 8 heads equally loaded, so stealing
 //     (next head, checked with a plain load first) only happens in the last few chunks;
 //   * the next chunk index is fetched BEFORE the current chunk is processed: the atomic's latency hides behind work.
+// Approximate-then-verify form of the slab test.  The six quotients are first formed with ONE v_rcp_f32 per axis
+// (relative error of x * rcp(d) vs the correctly rounded x / d: <= ~2.4e-7).  If the resulting tin/tout are separated --
+// and tout is away from zero -- by more than 1e-6 * sum|t_i| (4x that bound; a perturbation of max/min compositions never
+// exceeds the largest perturbation of their inputs), the reference's decision `!((tin > tout) || (tout < 0))` is already
+// determined and no IEEE division is needed.  Anything closer, and anything non-finite (zero direction components make
+// inf/NaN terms whose handling depends on std::min/std::max argument order), takes the exact path.  ~30 VALU instead of
+// ~100 per box test; the decision is bit-identical by construction (checked by the counter-equality tests).
+__device__ __forceinline__ bool box_hit_verified(const float *__restrict__ b, float ox, float oy, float oz, float dx, float dy, float dz,
+                                                 float rx, float ry, float rz) {
+    const float ax0 = (b[0] - ox) * rx, ax1 = (b[3] - ox) * rx;
+    const float ay0 = (b[1] - oy) * ry, ay1 = (b[4] - oy) * ry;
+    const float az0 = (b[2] - oz) * rz, az1 = (b[5] - oz) * rz;
+    const float tin = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
+    const float tout = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+    const float mag = ((fabsf(ax0) + fabsf(ax1)) + (fabsf(ay0) + fabsf(ay1))) + (fabsf(az0) + fabsf(az1));
+    const float e = 1e-6f * mag;
+    const bool finite = mag < 3.0e38f;                       // false for inf and NaN
+    const bool sure_hit = finite && (tout - tin > e) && (tout > e);
+    const bool sure_miss = finite && ((tin - tout > e) || (tout < -e));
+    if (sure_hit) return true;
+    if (sure_miss) return false;
+    return box_hit(b, ox, oy, oz, dx, dy, dz);
+}
+
 struct ShardedQueue {
     uint32_t *ctr;
     uint32_t total, chunk, nchunks, shard, tries, fetched, cur, cur_end;
@@ -208,6 +232,7 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                                             const float ox, const float oy, const float oz,      // ray origin
                                             const float dx, const float dy, const float dz,      // triangle-test direction
                                             const float bx, const float by, const float bz,      // box-test direction (dest - origin)
+                                            const float brx, const float bry, const float brz,   // v_rcp_f32 of it (approximate)
                                             float &best_t, int &best_f, bool &occluded,
                                             uint32_t &cnt_box, uint32_t &cnt_ref) {
     int sp = 0;
@@ -403,7 +428,7 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
             for (uint32_t c = 0; c < cnt; ++c) {
                 const uint32_t ci = nd.first + c;
                 const rt_node ch = nodes[ci];
-                const bool h = mine && box_hit(ch.bmin, ox, oy, oz, bx, by, bz);
+                const bool h = mine && box_hit_verified(ch.bmin, ox, oy, oz, bx, by, bz, brx, bry, brz);
                 RT_PROF_ADD(lane, 4, 1); RT_PROF_ADD(lane, 5, __popcll(__ballot(mine)));
                 if (COUNT && mine) cnt_box += h ? 2u : 1u;
                 const unsigned long long hm = __ballot(h);
@@ -464,10 +489,11 @@ __device__ __forceinline__ void walk(const rt_node &root, const rt_node *__restr
                                      const float extent, const WaveStack stk, const int lane, bool in_root,
                                      const float ox, const float oy, const float oz, const float dx, const float dy, const float dz,
                                      const float bx, const float by, const float bz,
+                                     const float brx, const float bry, const float brz,
                                      float &best_t, int &best_f, bool &occluded, uint32_t &cnt_box, uint32_t &cnt_ref) {
     if (FLAT) flat_walk<ANY, COUNT>(root, tris, in_root, ox, oy, oz, dx, dy, dz, best_t, best_f, occluded, cnt_box, cnt_ref);
     else packet_walk<ANY, COUNT>(nodes, tris, chunks, leaf_chunk0, extent, stk, lane, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz,
-                                 best_t, best_f, occluded, cnt_box, cnt_ref);
+                                 brx, bry, brz, best_t, best_f, occluded, cnt_box, cnt_ref);
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -540,7 +566,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
             const float sz = ((m[8] * n0 + m[9] * n1) + m[10] * n2) + m[11] * 1.0f;
             ox = cam.center[0]; oy = cam.center[1]; oz = cam.center[2];
             dx = sx - ox; dy = sy - oy; dz = sz - oz;          // direction = screen - origin (UNNORMALISED), flyscene.cpp:619
-            const bool pre = valid && box_hit(root.bmin, ox, oy, oz, dx, dy, dz);   // flyscene.cpp:576
+            const bool pre = valid && box_hit_verified(root.bmin, ox, oy, oz, dx, dy, dz, __builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz));   // flyscene.cpp:576
             c_cull += (valid && !pre) ? 1u : 0u;
             in_root = pre;
         } else {
@@ -555,12 +581,13 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
         // traceRay: boxIntersect(origin, origin + direction) -- the box-test direction is (o + d) - o (flyscene.cpp:655)
         const float bx = (ox + dx) - ox, by = (oy + dy) - oy, bz = (oz + dz) - oz;
         if (COUNT && in_root) c_box += 1;
-        in_root = in_root && box_hit(root.bmin, ox, oy, oz, bx, by, bz);
+        const float brx = __builtin_amdgcn_rcpf(bx), bry = __builtin_amdgcn_rcpf(by), brz = __builtin_amdgcn_rcpf(bz);
+        in_root = in_root && box_hit_verified(root.bmin, ox, oy, oz, bx, by, bz, brx, bry, brz);
 
         float best_t = 3.402823466e+38f;
         int best_f = -1;
         bool dummy = false;
-        walk<false, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz, best_t, best_f, dummy, c_box, c_ref);
+        walk<false, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz, brx, bry, brz, best_t, best_f, dummy, c_box, c_ref);
         const bool hit = valid && (best_f >= 0) && (static_cast<uint32_t>(best_f) < S.n_faces);
         const float hx = ox + best_t * dx, hy = oy + best_t * dy, hz = oz + best_t * dz;   // flyscene.cpp:695
 
@@ -575,10 +602,11 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
                 const float sdx = hx - px, sdy = hy - py, sdz = hz - pz;      // direction = hitPoint - origin
                 c_centre += act ? 1u : 0u;
                 if (COUNT && act) c_box += 1;
-                const bool sroot = act && box_hit(root.bmin, px, py, pz, sdx, sdy, sdz);
+                const float srx = __builtin_amdgcn_rcpf(sdx), sry = __builtin_amdgcn_rcpf(sdy), srz = __builtin_amdgcn_rcpf(sdz);
+                const bool sroot = act && box_hit_verified(root.bmin, px, py, pz, sdx, sdy, sdz, srx, sry, srz);
                 float t_unused = 0.f; int f_unused = -1;
                 bool occ = false;
-                walk<true, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz, t_unused, f_unused, occ, c_box, c_ref);
+                walk<true, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz, srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref);
                 lit = lit || (act && !occ);
             }
         }
@@ -673,10 +701,11 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restr
         const float ddx = hx - sx, ddy = hy - sy, ddz = hz - sz;
         c_rays += valid ? 1u : 0u;
         if (COUNT && valid) c_box += 1;
-        const bool sroot = valid && box_hit(root.bmin, sx, sy, sz, ddx, ddy, ddz);
+        const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
+        const bool sroot = valid && box_hit_verified(root.bmin, sx, sy, sz, ddx, ddy, ddz, srx, sry, srz);
         float t_unused = 0.f; int f_unused = -1;
         bool occ = false;
-        walk<true, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, sroot, sx, sy, sz, ddx, ddy, ddz, ddx, ddy, ddz, t_unused, f_unused, occ, c_box, c_ref);
+        walk<true, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, sroot, sx, sy, sz, ddx, ddy, ddz, ddx, ddy, ddz, srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref);
         const unsigned long long vm = __ballot(valid && !occ);
         if (N <= 64u) {
             if (s_in == 0u && slot < G && g < groups) {
@@ -937,9 +966,10 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_segments(const rt_node *__res
         const int j = valid ? i : 0;
         const float px = light[j * 3], py = light[j * 3 + 1], pz = light[j * 3 + 2];
         const float ddx = hit[j * 3] - px, ddy = hit[j * 3 + 1] - py, ddz = hit[j * 3 + 2] - pz;
-        const bool sroot = valid && box_hit(root.bmin, px, py, pz, ddx, ddy, ddz);
+        const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
+        const bool sroot = valid && box_hit_verified(root.bmin, px, py, pz, ddx, ddy, ddz, srx, sry, srz);
         float t_unused = 0.f; int f_unused = -1; bool occ = false; uint32_t c0 = 0, c1 = 0;
-        packet_walk<true, false>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, sroot, px, py, pz, ddx, ddy, ddz, ddx, ddy, ddz, t_unused, f_unused, occ, c0, c1);
+        packet_walk<true, false>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, sroot, px, py, pz, ddx, ddy, ddz, ddx, ddy, ddz, srx, sry, srz, t_unused, f_unused, occ, c0, c1);
         if (valid) vis[i] = occ ? 0 : 1;
     }
 }
