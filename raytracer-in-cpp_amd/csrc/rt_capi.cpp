@@ -19,7 +19,10 @@ namespace rtamd {
 void launch_trace(bool primary, bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DCam *camp, const DLights &L, const DFrame &F,
                   int level, int slot, const RayItem *rays_in, ShadeItem *items, Control *ctl, float4 *rec, int32_t *out_hit, float *out_t);
 void launch_shadow(bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
-                   const ShadeItem *items, Control *ctl, unsigned long long *vis);
+                   const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget);
+void launch_shadow_cont(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, const ShadeItem *items,
+                        Control *ctl, unsigned long long *vis, const ContTask *tasks_in, ContTask *tasks_out, uint32_t q_in, uint32_t q_out,
+                        uint32_t cap, uint32_t budget);
 void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level, int slot, int lslots,
                   const ShadeItem *items, Control *ctl, const unsigned long long *vis, float4 *rec, float *fres, RayItem *rays_out);
 void launch_resolve(int grid, hipStream_t st, const DFrame &F, const float4 *rec, const float *fres, float *out_rgb, uint8_t *out_u8);
@@ -49,6 +52,7 @@ struct rt_ctx {
     bool reflective = false;     // some material spawns bounce rays (illum 3,4,5,6,9)
     bool flat = false;           // the root is a small leaf (cube.obj): specialised stack-free kernels
     int grid_mult = 1;
+    int dyn_trace = 0;
     // frame buffers
     size_t cap_pix = 0;
     int cap_levels = 0;
@@ -56,6 +60,9 @@ struct rt_ctx {
     RayItem *d_rays[2] = {nullptr, nullptr};
     ShadeItem *d_items = nullptr;
     unsigned long long *d_vis = nullptr;
+    ContTask *d_tasks[2] = {nullptr, nullptr};   // continuation queues of k_shadow (tree scenes)
+    uint32_t task_cap = 1u << 20;
+    uint32_t shadow_budget = 40000u;            // estimated VALU instructions per unit before it hands work away (0 = off)
     float4 *d_rec = nullptr;
     float *d_fres = nullptr;
     Control *d_ctl = nullptr;
@@ -105,6 +112,8 @@ extern "C" rt_status rt_create(rt_ctx **out, int device) {
     if (hipSetDevice(device) != hipSuccess) { delete c; return RT_ERR_NO_DEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *dt = std::getenv("RT_TRACE_DYNAMIC")) c->dyn_trace = std::atoi(dt) != 0;
+    if (const char *sb = std::getenv("RT_SHADOW_BUDGET")) c->shadow_budget = static_cast<uint32_t>(std::atoi(sb));
     if (const char *gm = std::getenv("RT_GRID_MULT")) {          // tuning knob: grid = CUs x residency x mult
         const int m = std::atoi(gm);
         if (m > 0 && m <= 64) c->grid_mult = m;
@@ -132,6 +141,9 @@ static void free_frame(rt_ctx *c) {
     if (c->d_rays[1]) (void)hipFree(c->d_rays[1]);
     if (c->d_items) (void)hipFree(c->d_items);
     if (c->d_vis) (void)hipFree(c->d_vis);
+    if (c->d_tasks[0]) (void)hipFree(c->d_tasks[0]);
+    if (c->d_tasks[1]) (void)hipFree(c->d_tasks[1]);
+    c->d_tasks[0] = c->d_tasks[1] = nullptr;
     if (c->d_rec) (void)hipFree(c->d_rec);
     if (c->d_fres) (void)hipFree(c->d_fres);
     c->d_rays[0] = c->d_rays[1] = nullptr; c->d_items = nullptr; c->d_vis = nullptr; c->d_rec = nullptr; c->d_fres = nullptr;
@@ -446,6 +458,8 @@ static rt_status ensure_frame(rt_ctx *c, size_t npix, int levels, size_t vis_wor
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_rays[1]), np * sizeof(RayItem)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_items), np * sizeof(ShadeItem)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_vis), vw * sizeof(unsigned long long)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_tasks[0]), static_cast<size_t>(c->task_cap) * sizeof(ContTask)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_tasks[1]), static_cast<size_t>(c->task_cap) * sizeof(ContTask)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_rec), np * static_cast<size_t>(lv) * sizeof(float4)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_fres), np * static_cast<size_t>(lv) * sizeof(float)));
         c->cap_pix = np; c->cap_levels = lv; c->cap_vis = vw;
@@ -492,8 +506,16 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
         launch_trace(prim, count, c->flat, c->cus * (prim ? c->occ_trace_primary : c->occ_trace_rays), st, c->S, c->d_cam, L, F, level, 3 * level, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
                      level == 0 ? d_hit : nullptr, level == 0 ? d_t : nullptr);
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
-        launch_shadow(count, c->flat, c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, c->d_items, c->d_ctl, c->d_vis);
-        if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
+        launch_shadow(count, c->flat, c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, c->d_items, c->d_ctl, c->d_vis,
+                      c->d_tasks[0], c->task_cap, c->shadow_budget);
+        if (!c->flat && !count && c->shadow_budget != 0u) {
+            // heavy units handed their remaining sub-trees over: resume them (second round still budgeted, third finishes)
+            launch_shadow_cont(c->cus * c->occ_shadow, st, c->S, L, level, lslots, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[0], c->d_tasks[1], 0u, 1u,
+                               c->task_cap, c->shadow_budget);
+            launch_shadow_cont(c->cus * c->occ_shadow, st, c->S, L, level, lslots, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[1], nullptr, 1u, 0u,
+                               c->task_cap, 0u);
+        }
+        if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));   // after the whole shadow group (incl. continuations)
         launch_shade(c->cus * c->occ_shade, st, c->S, L, F, level, 3 * level + 2, lslots, c->d_items, c->d_ctl, c->d_vis, rec_l, fres_l, c->d_rays[(level + 1) & 1]);
         if (timed == 1) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
     }
@@ -531,6 +553,7 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
     HIPCHK(c, hipStreamSynchronize(st));
     Control h;
     HIPCHK(c, hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
+    if (std::getenv("RT_DEBUG")) std::fprintf(stderr, "RT_DEBUG level0: items %u tasks q0 %u q1 %u\n", h.n_items[0], h.n_tasks[0][0], h.n_tasks[0][1]);
     out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample;
     out->pixels = F.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;
 #ifdef RT_PROFILE
@@ -568,6 +591,7 @@ static rt_status make_frame(rt_ctx *c, const rt_params *p, DFrame *F) {
     F->tiles_x = (p->width + 7) / 8; F->tiles_y = (F->local_rows + 7) / 8;
     F->npix = static_cast<uint32_t>(F->local_rows) * static_cast<uint32_t>(p->width);
     F->max_depth = p->max_depth < 0 ? RT_MAX_DEPTH : p->max_depth;
+    F->dyn_trace = c->dyn_trace;
     return RT_OK;
 }
 
@@ -763,6 +787,7 @@ extern "C" rt_status rt_trace_rays(rt_ctx *c, const rt_lights *lights, int32_t m
     F.width = n; F.height = 1; F.local_rows = 1; F.row0 = 0; F.stripe = 1; F.rank = 0; F.nranks = 1;
     F.tiles_x = (n + 7) / 8; F.tiles_y = 1; F.npix = static_cast<uint32_t>(n);
     F.max_depth = max_depth < 0 ? RT_MAX_DEPTH : max_depth;
+    F.dyn_trace = c->dyn_trace;
     const size_t P = (static_cast<size_t>(L.n_samples) + 63) / 64;
     if ((s = ensure_frame(c, F.npix, F.max_depth + 1, static_cast<size_t>(F.npix) * L.n_lights * P)) != RT_OK) return s;
     std::vector<RayItem> rays(static_cast<size_t>(n));

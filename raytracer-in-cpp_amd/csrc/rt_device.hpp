@@ -71,6 +71,15 @@ struct alignas(16) ShadeItem {   // a lit closest hit waiting for its sample sha
 };
 static_assert(sizeof(ShadeItem) == 64, "ShadeItem must be 64 bytes");
 
+// A suspended piece of a shadow unit's traversal: the sub-tree under `node` for the rays in `mask` (lane mask of the
+// unit's wave).  Emitted when a unit exceeds its work budget, resumed by k_shadow_cont on whichever wave is free.
+struct alignas(16) ContTask {
+    uint32_t unit;
+    uint32_t node;
+    unsigned long long mask;
+};
+static_assert(sizeof(ContTask) == 16, "ContTask must be 16 bytes");
+
 // blend kinds stored in rec[].w (bit pattern of a uint32)
 enum : uint32_t {
     KIND_CONST = 0,      // terminal: rgb is the value (BACKGROUND, SHADOW or plain Phong)
@@ -117,6 +126,7 @@ struct DFrame {              // which pixels this launch covers
     int32_t tiles_x, tiles_y;
     uint32_t npix;           // local_rows * width
     int32_t max_depth;
+    int32_t dyn_trace;       // k_trace pulls tiles from the sharded queue instead of static striding
 };
 
 #define RT_QUEUE_SHARDS 8
@@ -127,6 +137,7 @@ struct Control {
     uint32_t queue[3 * (RT_MAX_DEPTH + 1) + 4][RT_QUEUE_SHARDS * 16];
     uint32_t n_items[RT_MAX_DEPTH + 1];              // lit hits per level
     uint32_t n_rays[RT_MAX_DEPTH + 2];               // bounce rays per level (n_rays[0] = rt_trace_rays input count)
+    uint32_t n_tasks[RT_MAX_DEPTH + 1][2];           // continuation tasks per level and queue
     unsigned long long rays_primary, rays_bounce, rays_centre, rays_sample, pixels_culled, shaded_hits;
     unsigned long long box_tests, leaf_tri_refs;              // k_trace (closest hit + light-centre rays)
     unsigned long long box_tests_shadow, leaf_tri_refs_shadow; // k_shadow (area-light sample rays)

@@ -200,6 +200,20 @@ __device__ __forceinline__ TriRec tri_load_uniform(const TriRec *p) {
     return t;
 }
 
+// How a packet walk starts and when it gives work away.
+struct WalkCtl {
+    bool resume;                      // start from (start_node, start_mask) instead of the root
+    uint32_t start_node;
+    unsigned long long start_mask;
+    uint32_t budget;                  // 0 = never flush; otherwise: estimated VALU instructions a unit may spend before its
+                                      // remaining stack entries are turned into continuation tasks
+    uint32_t unit;                    // unit id stored in the emitted tasks
+    ContTask *tasks;                  // output queue (capacity task_cap) and its counter
+    uint32_t *task_count;
+    uint32_t task_cap;
+};
+__device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, nullptr, nullptr, 0u}; }
+
 __device__ __forceinline__ float lane_f(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
@@ -228,7 +242,7 @@ __device__ unsigned long long *g_prof = nullptr;
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
                                             const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
-                                            const float extent, const WaveStack stk, const int lane, bool in_root,
+                                            const float extent, const WaveStack stk, const int lane, const WalkCtl wc, bool in_root,
                                             const float ox, const float oy, const float oz,      // ray origin
                                             const float dx, const float dy, const float dz,      // triangle-test direction
                                             const float bx, const float by, const float bz,      // box-test direction (dest - origin)
@@ -236,15 +250,35 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                                             float &best_t, int &best_f, bool &occluded,
                                             uint32_t &cnt_box, uint32_t &cnt_ref) {
     int sp = 0;
+    uint32_t spent = 0, budget = wc.budget;
     {
-        const unsigned long long m0 = __ballot(in_root);
+        unsigned long long m0 = __ballot(in_root);
+        if (wc.resume) m0 &= wc.start_mask;
         if (m0 == 0ull) return;
-        if (COUNT && in_root) cnt_box += 1;      // BoxTree::intersect re-tests the root it was just given
-        stk.node[0] = 0u;
+        if (COUNT && in_root && !wc.resume) cnt_box += 1;      // BoxTree::intersect re-tests the root it was just given
+        stk.node[0] = wc.resume ? wc.start_node : 0u;
         stk.mask[0] = m0;
         sp = 1;
     }
     while (sp > 0) {
+        if (budget != 0u && spent > budget) {
+            // Over budget: hand the remaining sub-trees to other waves.  One atomic reserves `sp` slots; if the queue
+            // is full the reservation is undone and the unit simply finishes here.
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(wc.task_count, static_cast<uint32_t>(sp));
+            base = uniform_u32(base);
+            if (base + static_cast<uint32_t>(sp) <= wc.task_cap) {
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < sp; i += 64) {
+                    ContTask t;
+                    t.unit = wc.unit; t.node = stk.node[i]; t.mask = stk.mask[i];
+                    wc.tasks[base + static_cast<uint32_t>(i)] = t;
+                }
+                return;
+            }
+            if (lane == 0) atomicSub(wc.task_count, static_cast<uint32_t>(sp));
+            budget = 0u;
+        }
         --sp;
         __builtin_amdgcn_wave_barrier();
         const uint32_t ni = uniform_u32(stk.node[sp]);
@@ -262,6 +296,8 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
             // lanes=triangles estimate: one bound test per chunk + live rays x the share of chunks a ray cannot skip
             const bool tri_mode = nchunk * RT_COST_CHUNK_TEST + static_cast<uint32_t>(__popcll(live)) * ((nchunk + 2u) / 3u) * RT_COST_TRI_MODE
                                   < cnt * RT_COST_RAY_MODE;
+            spent += tri_mode ? nchunk * RT_COST_CHUNK_TEST + static_cast<uint32_t>(__popcll(live)) * ((nchunk + 2u) / 3u) * RT_COST_TRI_MODE
+                              : cnt * RT_COST_RAY_MODE;
             RT_PROF_ADD(lane, tri_mode ? 7 : 6, 1);
             if (tri_mode) {
                 RT_PROF_ADD(lane, 8, __popcll(live));
@@ -425,6 +461,7 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                 }
             }
         } else {
+            spent += cnt * 35u;
             for (uint32_t c = 0; c < cnt; ++c) {
                 const uint32_t ci = nd.first + c;
                 const rt_node ch = nodes[ci];
@@ -486,13 +523,13 @@ __device__ __forceinline__ void flat_walk(const rt_node &root, const TriRec *__r
 template <bool ANY, bool COUNT, bool FLAT>
 __device__ __forceinline__ void walk(const rt_node &root, const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
                                      const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
-                                     const float extent, const WaveStack stk, const int lane, bool in_root,
+                                     const float extent, const WaveStack stk, const int lane, const WalkCtl wc, bool in_root,
                                      const float ox, const float oy, const float oz, const float dx, const float dy, const float dz,
                                      const float bx, const float by, const float bz,
                                      const float brx, const float bry, const float brz,
                                      float &best_t, int &best_f, bool &occluded, uint32_t &cnt_box, uint32_t &cnt_ref) {
     if (FLAT) flat_walk<ANY, COUNT>(root, tris, in_root, ox, oy, oz, dx, dy, dz, best_t, best_f, occluded, cnt_box, cnt_ref);
-    else packet_walk<ANY, COUNT>(nodes, tris, chunks, leaf_chunk0, extent, stk, lane, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz,
+    else packet_walk<ANY, COUNT>(nodes, tris, chunks, leaf_chunk0, extent, stk, lane, wc, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz,
                                  brx, bry, brz, best_t, best_f, occluded, cnt_box, cnt_ref);
 }
 
@@ -540,7 +577,8 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
 
     uint32_t c_rays = 0, c_cull = 0, c_centre = 0, c_box = 0, c_ref = 0;
     ShardedQueue q;
-    q.init_static(ntiles, gridDim.x * RT_WAVES, uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave)), lane);
+    if (F.dyn_trace) q.init(ctl->queue[ctr_slot], ntiles, gridDim.x * RT_WAVES, blockIdx.x, lane);
+    else q.init_static(ntiles, gridDim.x * RT_WAVES, uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave)), lane);
     for (uint32_t tile = 0; q.next(tile);) {
 
         bool valid;
@@ -587,7 +625,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
         float best_t = 3.402823466e+38f;
         int best_f = -1;
         bool dummy = false;
-        walk<false, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz, brx, bry, brz, best_t, best_f, dummy, c_box, c_ref);
+        walk<false, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, walk_plain(), in_root, ox, oy, oz, dx, dy, dz, bx, by, bz, brx, bry, brz, best_t, best_f, dummy, c_box, c_ref);
         const bool hit = valid && (best_f >= 0) && (static_cast<uint32_t>(best_f) < S.n_faces);
         const float hx = ox + best_t * dx, hy = oy + best_t * dy, hz = oz + best_t * dz;   // flyscene.cpp:695
 
@@ -606,7 +644,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
                 const bool sroot = act && box_hit_verified(root.bmin, px, py, pz, sdx, sdy, sdz, srx, sry, srz);
                 float t_unused = 0.f; int f_unused = -1;
                 bool occ = false;
-                walk<true, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz, srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref);
+                walk<true, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, walk_plain(), sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz, srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref);
                 lit = lit || (act && !occ);
             }
         }
@@ -651,12 +689,23 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
 // One wave = the N samples of one (hit, light) pair (N = 64), several pairs per wave (N < 64) or
 // ceil(N/64) wave passes per pair (N > 64).  Output: one visibility bit per sample.
 // ======================================================================================================
-template <bool COUNT, bool FLAT>
+// Work-budget continuation (tree scenes): a unit whose estimated work exceeds `budget` turns the rest of its traversal
+// stack into ContTask records (node, lane mask) in `tasks_out`; k_shadow<.., CONT=true> resumes those sub-trees on
+// whichever wave is free and merges the occluded bits into `vis` with atomicAnd.  Measured need: on dodgeColorTest a
+// few units cost 40x the mean and waves were resident for only 50 % of the kernel.
+struct ShadowQueues {
+    const ContTask *tasks_in;     // CONT only
+    ContTask *tasks_out;          // nullptr: never flush
+    uint32_t q_in, q_out;         // indices into Control::n_tasks[level]
+    uint32_t cap, budget;
+};
+
+template <bool COUNT, bool FLAT, bool CONT>
 __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
                                                           const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                                            const DScene S, const DLights L, const int level, const int ctr_slot,
                                                            const int lslots, const ShadeItem *__restrict__ items,
-                                                           Control *__restrict__ ctl, unsigned long long *__restrict__ vis) {
+                                                           Control *__restrict__ ctl, unsigned long long *vis, const ShadowQueues Q) {
     __shared__ uint4 s_stage[RT_WAVES * RT_STAGE_TRIS * 5];
     __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
     __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
@@ -672,14 +721,34 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restr
     const rt_node root = nodes[0];
     const uint32_t slot = N <= 64u ? static_cast<uint32_t>(lane) / N : 0u;
     const uint32_t s_in = N <= 64u ? static_cast<uint32_t>(lane) - slot * N : static_cast<uint32_t>(lane);
+    const unsigned long long low = N >= 64u ? ~0ull : ((1ull << N) - 1ull);
 
     uint32_t c_rays = 0, c_box = 0, c_ref = 0;
     ShardedQueue q;
-    q.init(ctl->queue[ctr_slot], static_cast<uint32_t>(units), gridDim.x * RT_WAVES, blockIdx.x, lane);
-    for (uint32_t unit = 0; q.next(unit);) {
+    uint32_t n_work = 0;
+    if (CONT) {
+        n_work = ctl->n_tasks[level][Q.q_in];
+        if (n_work > Q.cap) n_work = Q.cap;
+        q.init_static(n_work, gridDim.x * RT_WAVES, uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave)), lane);
+    } else {
+        q.init(ctl->queue[ctr_slot], static_cast<uint32_t>(units), gridDim.x * RT_WAVES, blockIdx.x, lane);
+    }
+    for (uint32_t work = 0; q.next(work);) {
 #ifdef RT_PROFILE
         const long long prof_t0 = clock64();
 #endif
+        uint32_t unit = work;
+        WalkCtl wc = walk_plain();
+        if (CONT) {
+            const ContTask task = Q.tasks_in[work];
+            unit = uniform_u32(task.unit);
+            wc.resume = true;
+            wc.start_node = uniform_u32(task.node);
+            wc.start_mask = uniform_u64(task.mask);
+        }
+        if (!FLAT && Q.tasks_out != nullptr && Q.budget != 0u) {
+            wc.budget = Q.budget; wc.unit = unit; wc.tasks = Q.tasks_out; wc.task_count = &ctl->n_tasks[level][Q.q_out]; wc.task_cap = Q.cap;
+        }
         uint32_t g, s, pass = 0;
         bool valid;
         if (N <= 64u) {
@@ -699,21 +768,37 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restr
         float sx, sy, sz;
         light_sample(L, px, py, pz, static_cast<int>(s), sx, sy, sz);
         const float ddx = hx - sx, ddy = hy - sy, ddz = hz - sz;
-        c_rays += valid ? 1u : 0u;
-        if (COUNT && valid) c_box += 1;
         const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
-        const bool sroot = valid && box_hit_verified(root.bmin, sx, sy, sz, ddx, ddy, ddz, srx, sry, srz);
+        const unsigned long long vis_index = N <= 64u ? static_cast<unsigned long long>(g) : static_cast<unsigned long long>(g) * P + pass;
+        bool sroot;
+        if (CONT) {
+            // the root test was passed when the task was emitted (the mask only holds lanes that reached `node`); rays
+            // another piece of this unit already found occluded are dropped
+            const unsigned long long seen = valid ? vis[vis_index] : 0ull;
+            sroot = valid && (((seen >> s_in) & 1ull) != 0ull);
+        } else {
+            c_rays += valid ? 1u : 0u;
+            if (COUNT && valid) c_box += 1;
+            sroot = valid && box_hit_verified(root.bmin, sx, sy, sz, ddx, ddy, ddz, srx, sry, srz);
+        }
         float t_unused = 0.f; int f_unused = -1;
         bool occ = false;
-        walk<true, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, sroot, sx, sy, sz, ddx, ddy, ddz, ddx, ddy, ddz, srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref);
-        const unsigned long long vm = __ballot(valid && !occ);
-        if (N <= 64u) {
-            if (s_in == 0u && slot < G && g < groups) {
-                const unsigned long long low = N == 64u ? ~0ull : ((1ull << N) - 1ull);
-                vis[g] = (vm >> (slot * N)) & low;
+        walk<true, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, wc, sroot, sx, sy, sz, ddx, ddy, ddz, ddx, ddy, ddz, srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref);
+        if (CONT) {
+            const unsigned long long om = __ballot(valid && occ);
+            if (N <= 64u) {
+                const unsigned long long word = (om >> (slot * N)) & low;
+                if (s_in == 0u && slot < G && g < groups && word != 0ull) atomicAnd(&vis[vis_index], ~word);
+            } else if (lane == 0 && om != 0ull) {
+                atomicAnd(&vis[vis_index], ~om);
             }
-        } else if (lane == 0) {
-            vis[static_cast<unsigned long long>(g) * P + pass] = vm;
+        } else {
+            const unsigned long long vm = __ballot(valid && !occ);
+            if (N <= 64u) {
+                if (s_in == 0u && slot < G && g < groups) vis[vis_index] = (vm >> (slot * N)) & low;
+            } else if (lane == 0) {
+                vis[vis_index] = vm;
+            }
         }
 #ifdef RT_PROFILE
         {   // per-unit cycle histogram: prof[16 + log2(cycles)], max in prof[9], sum in prof[10], count in prof[11]
@@ -835,10 +920,16 @@ __global__ __launch_bounds__(256) void k_shade(const DScene S, const DLights L, 
                 const unsigned long long *vw = vis + (static_cast<unsigned long long>(idx) * static_cast<unsigned long long>(lslots) + static_cast<unsigned long long>(l)) * P;
                 float sum = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
                 unsigned long long word = 0ull;
+                // The per-sample term is evaluated for EVERY sample and added as `visible ? term : +0` in sample order --
+                // identical to skipping invisible samples (x + 0 == x for the non-negative accumulators) but branch-free,
+                // so two samples' independent sqrt/divide chains can be in flight (ILP at 3 waves per SIMD).
+                const float lkd0 = L.color[0] * mat.kd[0], lkd1 = L.color[1] * mat.kd[1], lkd2 = L.color[2] * mat.kd[2];
+                const float lks0 = L.color[0] * mat.ks[0], lks1 = L.color[1] * mat.ks[1], lks2 = L.color[2] * mat.ks[2];
+#pragma unroll 2
                 for (uint32_t s = 0; s < N; ++s) {
                     if ((s & 63u) == 0u) word = vw[s >> 6];
-                    if (!((word >> (s & 63u)) & 1ull)) continue;
-                    sum += 1.0f;
+                    const bool visible = ((word >> (s & 63u)) & 1ull) != 0ull;
+                    sum += visible ? 1.0f : 0.0f;
                     float sx, sy, sz;
                     light_sample(L, px, py, pz, static_cast<int>(s), sx, sy, sz);
                     float ldx = sx - hx, ldy = sy - hy, ldz = sz - hz;
@@ -850,9 +941,10 @@ __global__ __launch_bounds__(256) void k_shade(const DScene S, const DLights L, 
                     normalize3(rx, ry, rz);
                     const float cosphi = smax(0.0f, dot3(ex, ey, ez, -1.0f * rx, -1.0f * ry, -1.0f * rz));
                     const float pw = pow_shininess(cosphi, mat.shininess);
-                    cr = cr + ((L.color[0] * mat.kd[0]) * costheta + (L.color[0] * mat.ks[0]) * pw);
-                    cg = cg + ((L.color[1] * mat.kd[1]) * costheta + (L.color[1] * mat.ks[1]) * pw);
-                    cb = cb + ((L.color[2] * mat.kd[2]) * costheta + (L.color[2] * mat.ks[2]) * pw);
+                    const float tr_ = lkd0 * costheta + lks0 * pw, tg_ = lkd1 * costheta + lks1 * pw, tb_ = lkd2 * costheta + lks2 * pw;
+                    cr = cr + (visible ? tr_ : 0.0f);
+                    cg = cg + (visible ? tg_ : 0.0f);
+                    cb = cb + (visible ? tb_ : 0.0f);
                 }
                 const float a = sum / static_cast<float>(N), b = 1.3f / static_cast<float>(N);
                 fr = fr + (cr * a) * b;
@@ -969,7 +1061,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_segments(const rt_node *__res
         const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
         const bool sroot = valid && box_hit_verified(root.bmin, px, py, pz, ddx, ddy, ddz, srx, sry, srz);
         float t_unused = 0.f; int f_unused = -1; bool occ = false; uint32_t c0 = 0, c1 = 0;
-        packet_walk<true, false>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, sroot, px, py, pz, ddx, ddy, ddz, ddx, ddy, ddz, srx, sry, srz, t_unused, f_unused, occ, c0, c1);
+        packet_walk<true, false>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, walk_plain(), sroot, px, py, pz, ddx, ddy, ddz, ddx, ddy, ddz, srx, sry, srz, t_unused, f_unused, occ, c0, c1);
         if (valid) vis[i] = occ ? 0 : 1;
     }
 }
@@ -992,11 +1084,11 @@ void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow
     if (flat) {
         *trace_primary = q(k_trace<true, false, true>, RT_WAVES * 64, 4);
         *trace_rays = q(k_trace<false, false, true>, RT_WAVES * 64, 4);
-        *shadow = q(k_shadow<false, true>, RT_WAVES * 64, 4);
+        *shadow = q(k_shadow<false, true, false>, RT_WAVES * 64, 4);
     } else {
         *trace_primary = q(k_trace<true, false, false>, RT_WAVES * 64, 4);
         *trace_rays = q(k_trace<false, false, false>, RT_WAVES * 64, 4);
-        *shadow = q(k_shadow<false, false>, RT_WAVES * 64, 4);
+        *shadow = q(k_shadow<false, false, false>, RT_WAVES * 64, 4);
     }
     *shade = q(k_shade, 256, 2);
 }
@@ -1021,12 +1113,23 @@ void launch_trace(bool primary, bool count, bool flat, int grid, hipStream_t st,
     }
 }
 
-#define RT_LAUNCH_SHADOW(C, F) hipLaunchKernelGGL((k_shadow<C, F>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, L, level, slot, lslots, items, ctl, vis)
+#define RT_LAUNCH_SHADOW(C, F, K) hipLaunchKernelGGL((k_shadow<C, F, K>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, L, level, slot, lslots, items, ctl, vis, Q)
 void launch_shadow(bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
-                   const ShadeItem *items, Control *ctl, unsigned long long *vis) {
+                   const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget) {
     const dim3 g(grid), b(RT_WAVES * 64);
-    if (count) { if (flat) RT_LAUNCH_SHADOW(true, true); else RT_LAUNCH_SHADOW(true, false); }
-    else { if (flat) RT_LAUNCH_SHADOW(false, true); else RT_LAUNCH_SHADOW(false, false); }
+    const ShadowQueues Q{nullptr, (flat || count) ? nullptr : tasks_out, 0u, 0u, cap, (flat || count) ? 0u : budget};
+    if (count) { if (flat) RT_LAUNCH_SHADOW(true, true, false); else RT_LAUNCH_SHADOW(true, false, false); }
+    else { if (flat) RT_LAUNCH_SHADOW(false, true, false); else RT_LAUNCH_SHADOW(false, false, false); }
+}
+
+// resumes the tasks of queue q_in; a unit that is still over budget flushes into queue q_out (tasks_out == nullptr: finishes)
+void launch_shadow_cont(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, const ShadeItem *items,
+                        Control *ctl, unsigned long long *vis, const ContTask *tasks_in, ContTask *tasks_out, uint32_t q_in, uint32_t q_out,
+                        uint32_t cap, uint32_t budget) {
+    const dim3 g(grid), b(RT_WAVES * 64);
+    const int slot = 0;
+    const ShadowQueues Q{tasks_in, tasks_out, q_in, q_out, cap, tasks_out ? budget : 0u};
+    RT_LAUNCH_SHADOW(false, false, true);
 }
 
 void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level, int slot, int lslots,
