@@ -53,15 +53,22 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ray-trace path has no CPU fallback")
+    # RT_DIST_BACKEND=gloo rehearses the N > 1 path on a ONE-GPU box: every rank renders its stripes on GPU 0 and the
+    # gather runs over gloo on host copies.  The real path (default) is one rank per GPU with RCCL ("nccl").
+    backend = os.environ.get("RT_DIST_BACKEND", "nccl")
+    gpu_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the ray-trace path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    on_host = world > 1 and backend != "nccl"       # collectives on CPU tensors (rehearsal only)
 
     if args.scene == "wavy":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -75,7 +82,7 @@ def main():
     W, H, G, D, S = args.width, args.height, args.grid, args.depth, args.stripe
 
     hs = pkg.HostScene(scene_path, 1000, 15)
-    ctx = pkg.Context(local_rank)
+    ctx = pkg.Context(gpu_index)
     ctx.upload(hs)
     lib = ctx.lib
     cam = pkg.default_camera(W, H)
@@ -100,12 +107,24 @@ def main():
                                   C.byref(stats) if stats is not None else None)
         capi.check(lib, ctx.handle, st, "rt_render_device")
 
+    def gather_rows():
+        src = out_u8.cpu() if on_host else out_u8
+        bufs = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
+        dist.gather(src, gather_list=bufs, dst=0)         # the single RCCL exchange of the frame
+        return bufs
+
+    def reduce_(t, op):
+        if on_host:
+            c = t.cpu()
+            dist.all_reduce(c, op=op)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=op)
+
     def step(p):
         render(p)
         if world > 1:
-            bufs = [torch.empty_like(out_u8) for _ in range(world)] if rank == 0 else None
-            dist.gather(out_u8, gather_list=bufs, dst=0)     # the single RCCL exchange of the frame
-            return bufs
+            return gather_rows()
         return None
 
     # ---- untimed: algorithmic counters of this rank's rows (no-early-out counting variants) ----------------
@@ -117,7 +136,7 @@ def main():
                              cnt.rays_sample, cnt.rays_primary, cnt.rays_centre, cnt.rays_bounce, cnt.pixels_culled],
                             dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
+        reduce_(counters, dist.ReduceOp.SUM)
     tot = [int(x) for x in counters.tolist()]
     rays_frame = tot[0]
 
@@ -142,7 +161,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        reduce_(elapsed, dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     tim = capi.rt_stats()
     capi.check(lib, ctx.handle, lib.rt_timing_collect(ctx.handle, C.byref(tim)), "rt_timing_collect")
@@ -166,8 +185,7 @@ def main():
         for f in range(args.steps):
             g.launch(cams[f], stream.cuda_stream)
             if world > 1:
-                bufs = [torch.empty_like(out_u8) for _ in range(world)] if rank == 0 else None
-                dist.gather(out_u8, gather_list=bufs, dst=0)
+                gather_rows()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -176,8 +194,7 @@ def main():
         for f in range(args.steps):               # same camera as the timed region: the launch-overhead comparison
             g.launch(cam, stream.cuda_stream)
             if world > 1:
-                bufs = [torch.empty_like(out_u8) for _ in range(world)] if rank == 0 else None
-                dist.gather(out_u8, gather_list=bufs, dst=0)
+                gather_rows()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()

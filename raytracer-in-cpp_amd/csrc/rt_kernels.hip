@@ -214,6 +214,27 @@ struct WalkCtl {
 };
 __device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, nullptr, nullptr, 0u}; }
 
+__device__ __forceinline__ TriRec tri_from_regs(const u32x16 &lo, const u32x4 &hi) {
+    TriRec t;
+    t.ax = __uint_as_float(lo[0]); t.ay = __uint_as_float(lo[1]); t.az = __uint_as_float(lo[2]);
+    t.e0x = __uint_as_float(lo[3]); t.e0y = __uint_as_float(lo[4]); t.e0z = __uint_as_float(lo[5]);
+    t.e1x = __uint_as_float(lo[6]); t.e1y = __uint_as_float(lo[7]); t.e1z = __uint_as_float(lo[8]);
+    t.nx = __uint_as_float(lo[9]); t.ny = __uint_as_float(lo[10]); t.nz = __uint_as_float(lo[11]);
+    t.nA = __uint_as_float(lo[12]); t.d00 = __uint_as_float(lo[13]); t.d01 = __uint_as_float(lo[14]); t.d11 = __uint_as_float(lo[15]);
+    t.inv_denom = __uint_as_float(hi[0]); t.face = hi[1]; t.flags = hi[2]; t.pad = 0u;
+    return t;
+}
+// two consecutive records (p[0], p[1]) with ONE wait: the caller tests both in straight-line code, which puts two
+// independent division/dot-product chains in flight per wave
+__device__ __forceinline__ void tri_load_uniform2(const TriRec *p, TriRec &a, TriRec &b) {
+    u32x16 lo0, lo1;
+    u32x4 hi0, hi1;
+    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x40\n\ts_load_dwordx16 %2, %4, 0x50\n\ts_load_dwordx4 %3, %4, 0x90\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(lo0), "=&s"(hi0), "=&s"(lo1), "=&s"(hi1) : "s"(p) : "memory");
+    a = tri_from_regs(lo0, hi0);
+    b = tri_from_regs(lo1, hi1);
+}
+
 __device__ __forceinline__ float lane_f(float v, int src_lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
@@ -433,10 +454,17 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                     }
                 };
                 if (cnt <= RT_SCALAR_LEAF_MAX) {
-                    for (uint32_t k = 0; k < cnt; ++k) {
-                        const TriRec tr = tri_load_uniform(T + k);
+                    uint32_t k = 0;
+                    for (; k + 1u < cnt; k += 2u) {
+                        TriRec ta, tb;
+                        tri_load_uniform2(T + k, ta, tb);
+                        RT_PROF_ADD(lane, 0, 2); RT_PROF_ADD(lane, 1, 2 * __popcll(__ballot(mine)));
+                        test_lane(ta);
+                        test_lane(tb);
+                    }
+                    if (k < cnt) {
                         RT_PROF_ADD(lane, 0, 1); RT_PROF_ADD(lane, 1, __popcll(__ballot(mine)));
-                        test_lane(tr);
+                        test_lane(tri_load_uniform(T + k));
                     }
                 } else {
                     for (uint32_t c0 = 0; c0 < cnt; c0 += RT_STAGE_TRIS) {
@@ -446,12 +474,16 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                         for (uint32_t q = static_cast<uint32_t>(lane); q < n * 5u; q += 64u) stk.stage[q] = src[q];
                         __builtin_amdgcn_wave_barrier();
                         const TriRec *staged = reinterpret_cast<const TriRec *>(stk.stage);
-                        TriRec cur = staged[0];
-                        for (uint32_t k = 0; k < n; ++k) {
-                            const TriRec nxt = staged[k + 1u < n ? k + 1u : k];
+                        uint32_t k = 0;
+                        for (; k + 1u < n; k += 2u) {       // two records per step: two independent chains in flight
+                            const TriRec ta = staged[k], tb = staged[k + 1u];
+                            RT_PROF_ADD(lane, 0, 2); RT_PROF_ADD(lane, 1, 2 * __popcll(__ballot(mine)));
+                            test_lane(ta);
+                            test_lane(tb);
+                        }
+                        if (k < n) {
                             RT_PROF_ADD(lane, 0, 1); RT_PROF_ADD(lane, 1, __popcll(__ballot(mine)));
-                            test_lane(cur);
-                            cur = nxt;
+                            test_lane(staged[k]);
                         }
                         if (ANY && !COUNT) {
                             mine = mine && !occluded;
@@ -491,33 +523,38 @@ __device__ __forceinline__ void flat_walk(const rt_node &root, const TriRec *__r
     if (COUNT && in_root) { cnt_box += 1; cnt_ref += cnt; }
     const TriRec *__restrict__ T = tris + root.first;
     bool mine = in_root;
-    for (uint32_t k = 0; k < cnt; ++k) {
-        const TriRec tr = tri_load_uniform(T + k);
-        {
-            // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 -- straight-line form: every lane evaluates the
-            // same operations (a zero d.n just produces inf/NaN that the final predicate rejects, exactly like the
-            // reference's early `return -72`), which removes the exec-mask juggling of nested branches.
-            const float dn = dot3(dx, dy, dz, tr.nx, tr.ny, tr.nz);
-            const float t = (tr.nA - dot3(ox, oy, oz, tr.nx, tr.ny, tr.nz)) / dn;
-            const float v2x = (ox + t * dx) - tr.ax, v2y = (oy + t * dy) - tr.ay, v2z = (oz + t * dz) - tr.az;
-            const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
-            const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
-            const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
-            const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
-            const bool ok = mine && !(ANY && (tr.flags & 1u)) && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f);
-            if (ANY) {
-                occluded = occluded || (ok && t < 0.98f);
-            } else {
-                const bool better = ok && (t < best_t || (t == best_t && static_cast<int>(tr.face) < best_f));
-                best_t = better ? t : best_t;
-                best_f = better ? static_cast<int>(tr.face) : best_f;
-            }
+    auto test_one = [&](const TriRec &tr) {
+        // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 -- straight-line form: every lane evaluates the same
+        // operations (a zero d.n just produces inf/NaN that the final predicate rejects, exactly like the reference's early
+        // `return -72`), which removes the exec-mask juggling of nested branches.
+        const float dn = dot3(dx, dy, dz, tr.nx, tr.ny, tr.nz);
+        const float t = (tr.nA - dot3(ox, oy, oz, tr.nx, tr.ny, tr.nz)) / dn;
+        const float v2x = (ox + t * dx) - tr.ax, v2y = (oy + t * dy) - tr.ay, v2z = (oz + t * dz) - tr.az;
+        const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
+        const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
+        const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
+        const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
+        const bool ok = mine && !(ANY && (tr.flags & 1u)) && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f);
+        if (ANY) {
+            occluded = occluded || (ok && t < 0.98f);
+        } else {
+            const bool better = ok && (t < best_t || (t == best_t && static_cast<int>(tr.face) < best_f));
+            best_t = better ? t : best_t;
+            best_f = better ? static_cast<int>(tr.face) : best_f;
         }
-        if (ANY && !COUNT && (k & 7u) == 7u) {
+    };
+    uint32_t k = 0;
+    for (; k + 1u < cnt; k += 2u) {          // two records per step: two independent chains in flight
+        TriRec ta, tb;
+        tri_load_uniform2(T + k, ta, tb);
+        test_one(ta);
+        test_one(tb);
+        if (ANY && !COUNT && (k & 6u) == 6u) {
             mine = mine && !occluded;
-            if (__ballot(mine) == 0ull) break;
+            if (__ballot(mine) == 0ull) return;
         }
     }
+    if (k < cnt) test_one(tri_load_uniform(T + k));
 }
 
 template <bool ANY, bool COUNT, bool FLAT>
