@@ -351,3 +351,77 @@ def test_cfg4_million_triangle_mesh_4k_depth8_256_samples(rt, oracle, tmp_path):
     assert np.array_equal(out.view(np.uint32), a.view(np.uint32))
     assert rays == st_full
     fs.ctx.close()
+
+
+def test_multiple_lights_and_point_mode(rt, oracle, scenes):
+    """L = 3 lights (incl. one added at the camera centre like Flyscene::addLight) in area and point mode."""
+    for name in ("cube.obj", "dodgeColorTest.obj"):
+        path = os.path.join(scenes, name)
+        fs = rt.Flyscene(scene_path=path)
+        fs.initialize(200, 120, True, False)
+        fs.lights = [(-1.0, 1.0, 1.0), (0.8, 0.4, 1.5)]
+        fs.addLight()                                   # camera centre (0,0,2)
+        assert len(fs.lights) == 3
+        osc = oracle.load_scene(path)
+        for area in (True, False):
+            fs.areaLight, fs.pointLight = (True, False) if area else (True, True)
+            fs.usteps = fs.vsteps = 5
+            fs.max_depth = 3
+            rgb = fs.raytraceScene(200, 120, write_ppm=False, want_hits=True, collect_stats=True)
+            L = oracle.lights(area=area, usteps=5, vsteps=5, points=fs.lights)
+            ref, rhits, ost = osc.render(oracle.camera(200, 120), L, 200, 120, max_depth=3, threads=8, want_hits=True)
+            assert_frame_parity(oracle, rgb, fs.hits, ref, rhits)
+            st = fs.stats
+            assert (st.rays_centre, st.rays_sample, st.box_tests, st.leaf_tri_refs) == (ost.rays_centre, ost.rays_sample, ost.box_tests, ost.leaf_tri_refs)
+        osc.close()
+        fs.ctx.close()
+
+
+def test_headless_cli_is_a_drop_in_for_main_cpp(rt, scenes, tmp_path):
+    """raytracer-in-cpp_amd/lib/rt_render: stdin switches like the reference (flyscene.cpp:31-34), writes result.ppm in the
+    working directory; the 256x256 cube frames must carry the reference's md5s."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(rt.capi.LIB_PATH), "rt_render")
+    assert os.path.exists(exe)
+    os.makedirs(tmp_path / "resources" / "models")
+    for f in ("cube.obj", "cube.mtl"):
+        (tmp_path / "resources" / "models" / f).write_bytes(open(os.path.join(scenes, f), "rb").read())
+    for stdin, md5 in (("1\n0\n", "a42b624a02bc71242389958ee09ac121"), ("1\n1\n", "316e7dacee3e88f9765225790d5c3241")):
+        r = subprocess.run([exe, "--size", "256", "256"], input=stdin.encode(), cwd=tmp_path, capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr.decode()[-400:]
+        assert b"ELAPSED TIME:" in r.stdout
+        assert hashlib.md5((tmp_path / "result.ppm").read_bytes()).hexdigest() == md5
+
+
+def test_error_paths_on_device(rt, scenes):
+    import ctypes as C
+    lib = rt.load_library()
+    ctx = rt.Context(0)
+    cam = rt.default_camera(64, 64)
+    L = rt.make_lights()
+    p = rt.make_params(64, 64)
+    out = np.zeros((64, 64, 3), np.float32)
+    st = rt.capi.rt_stats()
+    c = rt.capi
+    assert lib.rt_render(ctx.handle, C.byref(cam), C.byref(L), C.byref(p), out.ctypes.data_as(C.c_void_p), None, C.byref(st)) == c.RT_ERR_NO_SCENE
+    hs = rt.HostScene(os.path.join(scenes, "cube.obj"))
+    ctx.upload(hs)
+    bad = rt.make_lights()
+    bad.n_lights = 26
+    assert lib.rt_render(ctx.handle, C.byref(cam), C.byref(bad), C.byref(p), out.ctypes.data_as(C.c_void_p), None, C.byref(st)) == c.RT_ERR_INVALID
+    assert b"25" in lib.rt_last_error(ctx.handle)
+    p2 = rt.make_params(64, 64, row0=0, row1=65)
+    assert lib.rt_render(ctx.handle, C.byref(cam), C.byref(L), C.byref(p2), out.ctypes.data_as(C.c_void_p), None, C.byref(st)) == c.RT_ERR_INVALID
+    p3 = rt.make_params(64, 64, max_depth=16)
+    assert lib.rt_render(ctx.handle, C.byref(cam), C.byref(L), C.byref(p3), out.ctypes.data_as(C.c_void_p), None, C.byref(st)) == c.RT_ERR_UNSUPPORTED
+    assert lib.rt_render(ctx.handle, C.byref(cam), C.byref(L), C.byref(p), out.ctypes.data_as(C.c_void_p), None, C.byref(st)) == c.RT_OK
+    # a corrupted scene is rejected before any kernel sees it
+    view = rt.capi.rt_scene()
+    C.memmove(C.byref(view), C.byref(hs.view), C.sizeof(view))
+    refs = (C.c_uint32 * view.n_face_refs)(*[999999] * view.n_face_refs)
+    view.face_refs = C.cast(refs, C.POINTER(C.c_uint32))
+    assert lib.rt_upload_scene(ctx.handle, C.byref(view)) == c.RT_ERR_INVALID
+    bad_ctx = C.c_void_p()
+    assert lib.rt_create(C.byref(bad_ctx), 99) == c.RT_ERR_NO_DEVICE
+    ctx.close()
+    hs.close()
