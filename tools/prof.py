@@ -1,7 +1,9 @@
 # diagnostic: render one frame with the RT_PROFILE build and print executed-work counters
 import ctypes as C, os, sys
-os.environ["RT_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "raytracer-in-cpp_amd", "lib", "librt_mi355x_prof.so")
-sys.path.insert(0, "tests")
+os.environ["RT_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer-in-cpp_amd", "lib", "librt_mi355x_prof.so")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import rtpkg
 pkg = rtpkg.load()
 scene = sys.argv[1] if len(sys.argv) > 1 else "dodgeColorTest.obj"
@@ -10,7 +12,7 @@ if scene == "wavy":
     import scenes_gen
     path = scenes_gen.wavy_grid("/tmp/rt_wavy_prof", n=708)
 else:
-    path = os.path.join("tests/golden/scenes", scene)
+    path = os.path.join(ROOT, "tests/golden/scenes", scene)
 fs = pkg.Flyscene(scene_path=path)
 fs.initialize(w, h, True, False)
 fs.usteps = fs.vsteps = u
