@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes (separate from kernel-trace, per the pool's rules): usage tools_pmc.sh <scene> <tag>
+# PMC passes (separate from kernel-trace, per the pool's rules): usage tools/pmc.sh <scene> <tag>
 sc=${1:-dodge}; tag=${2:-pmc}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Produces the rocprofv3 --kernel-trace --stats summaries that profiles/ keeps (run through gpurun).
-# usage: tools_profile.sh <round-tag>
+# usage: tools/profile.sh <round-tag>
 tag=${1:-r01}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the bench kernels from the TCC PMC counters, separate passes (MI355X_MICROARCH.md §HBM / rocprofv3 PMC slots):
 #   pass 1: --pmc FETCH_SIZE    pass 2: --pmc WRITE_SIZE      (units: KiB; FETCH_SIZE under-reports wide 16-B/lane reads by 2x on gfx950)
-# usage: tools_traffic.sh <scene> <tag> [extra bench args]
+# usage: tools/traffic.sh <scene> <tag> [extra bench args]
 sc=${1:-cube}; tag=${2:-traffic}; shift 2
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
