@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--stripe", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="N > 1: eager launches + synchronous gather instead of graph replay + pipelined gather")
     ap.add_argument("--cpu-stride", type=int, default=0, help="oracle pixel stride for the CPU baseline (0 = auto)")
     args = ap.parse_args()
 
@@ -140,10 +141,54 @@ def main():
     tot = [int(x) for x in counters.tolist()]
     rays_frame = tot[0]
 
+    # ---- N > 1: the per-rank frame is ~1/N of the work, so launch overhead and the gather dominate.  The step is then
+    # a hipGraph REPLAY of the frame (one host call instead of 17 launches) and the gather is asynchronous and
+    # double-buffered: render i+1 overlaps gather i (all K gathers complete inside the timed region).  N = 1 keeps eager
+    # launches with per-kernel HIP events, as the roofline contract asks.
+    pipe = None
+    if world > 1 and not on_host and not args.eager:
+        try:
+            u8 = [out_u8, torch.zeros_like(out_u8)]
+            graphs = [pkg.FrameGraph(ctx, L, _p(0), out_rgb.data_ptr(), u8[i].data_ptr()) for i in range(2)]
+            recv = [[torch.empty_like(out_u8) for _ in range(world)] for _ in range(2)] if rank == 0 else [None, None]
+            pipe = {"u8": u8, "graphs": graphs, "recv": recv, "pending": []}
+        except Exception as e:        # fall back to the synchronous eager step
+            print(f"[bench] graph/pipeline setup failed on rank {rank}: {e}; using the eager step", file=sys.stderr)
+            pipe = None
+
+    def step_pipe(i):
+        b = i & 1
+        pend = pipe["pending"]
+        if len(pend) >= 2:
+            pend[-2].wait()                       # stream-level wait: buffer b was read by gather i-2
+        pipe["graphs"][b].launch(cam, stream.cuda_stream)
+        pend.append(dist.gather(pipe["u8"][b], gather_list=pipe["recv"][b], dst=0, async_op=True))
+
+    def drain_pipe():
+        for h in pipe["pending"]:
+            h.wait()
+        pipe["pending"].clear()
+
     # ---- warmup ----------------------------------------------------------------------------------------------
     p_timed = _p(2)           # deferred per-kernel HIP events on the launch stream, no host sync inside the step
-    for _ in range(args.warmup):
-        step(p_timed)
+    if pipe:
+        try:                                      # exercise every pipeline call (incl. the i-2 wait) before the timed region
+            for i in range(max(3, args.warmup)):
+                step_pipe(i)
+            drain_pipe()
+            torch.cuda.synchronize(dev)
+        except Exception as e:
+            print(f"[bench] pipelined step failed on rank {rank}: {e}; using the eager step", file=sys.stderr)
+            pipe = None
+    # every rank must take the same path (the collectives differ): agree on the minimum
+    if world > 1:
+        flag = torch.tensor([1.0 if pipe else 0.0], dtype=torch.float64, device=dev)
+        reduce_(flag, dist.ReduceOp.MIN)
+        if flag.item() < 0.5:
+            pipe = None
+    if not pipe:
+        for i in range(args.warmup):
+            step(p_timed)
     torch.cuda.synchronize(dev)
     warm = capi.rt_stats()
     lib.rt_timing_collect(ctx.handle, C.byref(warm))
@@ -153,8 +198,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(p_timed)
+    for i in range(args.steps):
+        if pipe:
+            step_pipe(i)
+        else:
+            step(p_timed)
+    if pipe:
+        drain_pipe()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -213,10 +263,17 @@ def main():
     value = rays_frame * K / elapsed / 1e6
     # roofline of the dominant kernel (k_shadow: area-light sample shadow rays), rank 0's launches.
     # achieved = algorithmic bytes per launch / average launch duration (HIP events on the launch stream).
+    timing_source = "HIP events on the launch stream inside the timed region"
+    if tim.launches_shadow == 0:          # graph replay (N > 1): no per-kernel events inside the timed region
+        tim = brk
+        timing_source = "one instrumented eager frame outside the timed region (the timed loop replays a hipGraph)"
+        K_t = 1
+    else:
+        K_t = K
     launches = max(1, tim.launches_shadow)
     avg_ms_shadow = tim.ms_shadow / launches
     alg_shadow_frame = BOX_BYTES * cnt.box_tests_shadow + TRI_REF_BYTES * cnt.leaf_tri_refs_shadow   # rank 0's rows
-    launches_per_frame = launches / K
+    launches_per_frame = launches / K_t
     alg_per_launch = alg_shadow_frame / launches_per_frame
     achieved = alg_per_launch / (avg_ms_shadow * 1e-3) / 1e9 if avg_ms_shadow > 0 else 0.0
     trace_alg = BOX_BYTES * (cnt.box_tests - cnt.box_tests_shadow) + TRI_REF_BYTES * (cnt.leaf_tri_refs - cnt.leaf_tri_refs_shadow)
@@ -241,7 +298,8 @@ def main():
         "note": "algorithmic bytes = 24 B x box tests + 52 B x leaf triangle refs in reference semantics (no early-out); "
                 "the scene is LDS/L2/scalar-cache resident, so this is not HBM traffic (see DESIGN.md)",
         "k_trace": {"achieved": round(trace_gbs, 1), "ms_per_frame": round(brk.ms_trace, 4)},
-        "ms_per_frame": {"shadow": round(tim.ms_shadow / K, 4), "device_total": round(tim.ms_total / K, 4),
+        "timing_source": timing_source,
+        "ms_per_frame": {"shadow": round(tim.ms_shadow / K_t, 4), "device_total": round(tim.ms_total / K_t, 4),
                          "instrumented_frame": {"trace": round(brk.ms_trace, 4), "shadow": round(brk.ms_shadow, 4),
                                                 "shade": round(brk.ms_shade, 4), "resolve": round(brk.ms_resolve, 4),
                                                 "total": round(brk.ms_total, 4)}},
@@ -254,7 +312,7 @@ def main():
         "config": {"workload": f"{W}x{H} depth {D} {G * G}-sample area light, {scene_file}, "
                                f"1 light, row stripes of {S} over {world} GPU(s)",
                    "width": W, "height": H, "max_depth": D, "samples": G * G, "scene": scene_file,
-                   "parallelism": f"rows{world}"},
+                   "parallelism": f"rows{world}", "step": ("hipGraph replay + pipelined RCCL gather" if pipe else ("eager launches" + (" + gather" if world > 1 else "")))},
         "rays_per_frame": rays_frame,
         "graph_replay_ms_per_frame_120_frame_yaw_path": (round(graph_ms, 4) if isinstance(graph_ms, float) else graph_ms),
         "graph_replay_ms_per_frame_same_camera": (round(graph_same_ms, 4) if isinstance(graph_same_ms, float) else graph_same_ms),
