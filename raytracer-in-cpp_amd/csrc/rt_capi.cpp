@@ -19,13 +19,16 @@ namespace rtamd {
 void launch_trace(bool primary, bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DCam *camp, const DLights &L, const DFrame &F,
                   int level, int slot, const RayItem *rays_in, ShadeItem *items, Control *ctl, float4 *rec, int32_t *out_hit, float *out_t);
 void launch_shadow(bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
-                   const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget);
+                   const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target);
 void launch_shadow_cont(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, const ShadeItem *items,
                         Control *ctl, unsigned long long *vis, const ContTask *tasks_in, ContTask *tasks_out, uint32_t q_in, uint32_t q_out,
                         uint32_t cap, uint32_t budget);
 void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level, int slot, int lslots,
                   const ShadeItem *items, Control *ctl, const unsigned long long *vis, float4 *rec, float *fres, RayItem *rays_out);
 void launch_resolve(int grid, hipStream_t st, const DFrame &F, const float4 *rec, const float *fres, float *out_rgb, uint8_t *out_u8);
+void launch_stage(bool primary, bool count, int stage, bool cont, int grid, hipStream_t st, const DScene &S, const DCam *camp, const DLights &L,
+                  const DFrame &Fr, int level, int lslots, const RayItem *rays_in, ShadeItem *items, Control *ctl, float4 *rec, int32_t *out_hit,
+                  float *out_t, unsigned long long *best, unsigned long long *lit, const TaskQueues &Q);
 void launch_segments(int grid, hipStream_t st, const DScene &S, int n, const float *hit, const float *light, uint8_t *vis);
 void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow, int *shade);
 void launch_set_prof(hipStream_t st, Control *ctl);
@@ -53,6 +56,7 @@ struct rt_ctx {
     bool flat = false;           // the root is a small leaf (cube.obj): specialised stack-free kernels
     int grid_mult = 1;
     int dyn_trace = 0;
+    int staged_trace = 1;        // tree scenes: closest / centre / finish kernels with continuation tasks instead of the fused k_trace
     // frame buffers
     size_t cap_pix = 0;
     int cap_levels = 0;
@@ -60,9 +64,13 @@ struct rt_ctx {
     RayItem *d_rays[2] = {nullptr, nullptr};
     ShadeItem *d_items = nullptr;
     unsigned long long *d_vis = nullptr;
+    unsigned long long *d_best = nullptr, *d_lit = nullptr;   // staged trace of tree scenes: closest-hit keys, centre-visibility masks
+    size_t cap_lit = 0, cap_best = 0;
     ContTask *d_tasks[2] = {nullptr, nullptr};   // continuation queues of k_shadow (tree scenes)
-    uint32_t task_cap = 1u << 20;
-    uint32_t shadow_budget = 40000u;            // estimated VALU instructions per unit before it hands work away (0 = off)
+    uint32_t task_cap = 1u << 21;
+    uint32_t trace_budget = 1000u;              // leaves above this estimated cost (VALU instructions) become tasks (0 = off)
+    uint32_t shadow_budget = 1500u;
+    uint32_t task_target = 0u;                  // estimated cost of one leaf-task piece (0 = same as the budget)
     float4 *d_rec = nullptr;
     float *d_fres = nullptr;
     Control *d_ctl = nullptr;
@@ -114,6 +122,9 @@ extern "C" rt_status rt_create(rt_ctx **out, int device) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *dt = std::getenv("RT_TRACE_DYNAMIC")) c->dyn_trace = std::atoi(dt) != 0;
     if (const char *sb = std::getenv("RT_SHADOW_BUDGET")) c->shadow_budget = static_cast<uint32_t>(std::atoi(sb));
+    if (const char *sg = std::getenv("RT_STAGED_TRACE")) c->staged_trace = std::atoi(sg) != 0;
+    if (const char *tt = std::getenv("RT_TASK_TARGET")) c->task_target = static_cast<uint32_t>(std::atoi(tt));
+    if (const char *tb = std::getenv("RT_TRACE_BUDGET")) c->trace_budget = static_cast<uint32_t>(std::atoi(tb));
     if (const char *gm = std::getenv("RT_GRID_MULT")) {          // tuning knob: grid = CUs x residency x mult
         const int m = std::atoi(gm);
         if (m > 0 && m <= 64) c->grid_mult = m;
@@ -141,6 +152,9 @@ static void free_frame(rt_ctx *c) {
     if (c->d_rays[1]) (void)hipFree(c->d_rays[1]);
     if (c->d_items) (void)hipFree(c->d_items);
     if (c->d_vis) (void)hipFree(c->d_vis);
+    if (c->d_best) (void)hipFree(c->d_best);
+    if (c->d_lit) (void)hipFree(c->d_lit);
+    c->d_best = c->d_lit = nullptr; c->cap_lit = 0; c->cap_best = 0;
     if (c->d_tasks[0]) (void)hipFree(c->d_tasks[0]);
     if (c->d_tasks[1]) (void)hipFree(c->d_tasks[1]);
     c->d_tasks[0] = c->d_tasks[1] = nullptr;
@@ -447,22 +461,28 @@ static rt_status check_lights(rt_ctx *c, const rt_lights *l, DLights *out) {
     return RT_OK;
 }
 
-static rt_status ensure_frame(rt_ctx *c, size_t npix, int levels, size_t vis_words) {
-    if (npix > c->cap_pix || levels > c->cap_levels || vis_words > c->cap_vis) {
+static rt_status ensure_frame(rt_ctx *c, size_t npix, int levels, size_t vis_words, size_t tiles, size_t lslots) {
+    const size_t lit_words = tiles * lslots, best_slots = tiles * 64;
+    if (npix > c->cap_pix || levels > c->cap_levels || vis_words > c->cap_vis || lit_words > c->cap_lit || best_slots > c->cap_best) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         const size_t np = npix > c->cap_pix ? npix : c->cap_pix;
         const int lv = levels > c->cap_levels ? levels : c->cap_levels;
         const size_t vw = vis_words > c->cap_vis ? vis_words : c->cap_vis;
+        const size_t lw = lit_words > c->cap_lit ? lit_words : c->cap_lit;
+        const size_t bs = best_slots > c->cap_best ? best_slots : c->cap_best;
         free_frame(c);
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_rays[0]), np * sizeof(RayItem)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_rays[1]), np * sizeof(RayItem)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_items), np * sizeof(ShadeItem)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_vis), vw * sizeof(unsigned long long)));
+        // staged trace: one 64-bit closest-hit key per ray slot of every 8x8 tile (tiles are padded to 64 lanes), lit masks per (tile, light)
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_best), (bs ? bs : 64) * sizeof(unsigned long long)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_lit), (lw ? lw : 1) * sizeof(unsigned long long)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_tasks[0]), static_cast<size_t>(c->task_cap) * sizeof(ContTask)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_tasks[1]), static_cast<size_t>(c->task_cap) * sizeof(ContTask)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_rec), np * static_cast<size_t>(lv) * sizeof(float4)));
         HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_fres), np * static_cast<size_t>(lv) * sizeof(float)));
-        c->cap_pix = np; c->cap_levels = lv; c->cap_vis = vw;
+        c->cap_pix = np; c->cap_levels = lv; c->cap_vis = vw; c->cap_lit = lw; c->cap_best = bs;
         ++c->frame_generation;
     }
     return RT_OK;
@@ -485,7 +505,8 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
     const int levels_run = c->reflective ? D + 1 : 1;
     const int lslots = L.n_lights;
     const size_t P = (static_cast<size_t>(L.n_samples) + 63) / 64;
-    rt_status s = ensure_frame(c, F.npix, D + 1, static_cast<size_t>(F.npix) * lslots * P);
+    const size_t tiles = std::max(static_cast<size_t>(F.tiles_x) * static_cast<size_t>(F.tiles_y), static_cast<size_t>(F.npix) / 64 + 1);
+    rt_status s = ensure_frame(c, F.npix, D + 1, static_cast<size_t>(F.npix) * lslots * P, tiles, static_cast<size_t>(lslots));
     if (s != RT_OK) return s;
     HIPCHK(c, hipMemsetAsync(c->d_ctl, 0, sizeof(Control), st));
     launch_set_prof(st, c->d_ctl);   // no-op unless built with -DRT_PROFILE
@@ -503,18 +524,32 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
         float4 *rec_l = c->d_rec + static_cast<size_t>(level) * F.npix;
         float *fres_l = c->d_fres + static_cast<size_t>(level) * F.npix;
         const bool prim = primary && level == 0;
-        launch_trace(prim, count, c->flat, c->cus * (prim ? c->occ_trace_primary : c->occ_trace_rays), st, c->S, c->d_cam, L, F, level, 3 * level, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
-                     level == 0 ? d_hit : nullptr, level == 0 ? d_t : nullptr);
+        const int tgrid = c->cus * (prim ? c->occ_trace_primary : c->occ_trace_rays);
+        int32_t *hit_l = level == 0 ? d_hit : nullptr;
+        float *t_l = level == 0 ? d_t : nullptr;
+        if (c->flat || !c->staged_trace) {
+            launch_trace(prim, count, c->flat, tgrid, st, c->S, c->d_cam, L, F, level, 3 * level, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l, hit_l, t_l);
+        } else {
+            // tree scenes: closest hit -> light-centre visibility -> finish; each traversal stage writes its big leaves as
+            // chunk-range tasks that a second launch spreads over all waves
+            const uint32_t B = count ? 0u : c->trace_budget, cap = c->task_cap;
+            for (int stage = 0; stage < 2; ++stage) {
+                const uint32_t q0 = static_cast<uint32_t>(stage);
+                launch_stage(prim, count, stage, false, tgrid, st, c->S, c->d_cam, L, F, level, lslots, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
+                             hit_l, t_l, c->d_best, c->d_lit, TaskQueues{nullptr, B ? c->d_tasks[stage] : nullptr, 0u, q0, cap, B, c->task_target});
+                if (B != 0u)
+                    launch_stage(prim, false, stage, true, tgrid, st, c->S, c->d_cam, L, F, level, lslots, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
+                                 hit_l, t_l, c->d_best, c->d_lit, TaskQueues{c->d_tasks[stage], nullptr, q0, 0u, cap, 0u});
+            }
+            launch_stage(prim, count, 2, false, tgrid, st, c->S, c->d_cam, L, F, level, lslots, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l, hit_l, t_l,
+                         c->d_best, c->d_lit, TaskQueues{nullptr, nullptr, 0u, 0u, cap, 0u});
+        }
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
         launch_shadow(count, c->flat, c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, c->d_items, c->d_ctl, c->d_vis,
-                      c->d_tasks[0], c->task_cap, c->shadow_budget);
-        if (!c->flat && !count && c->shadow_budget != 0u) {
-            // heavy units handed their remaining sub-trees over: resume them (second round still budgeted, third finishes)
-            launch_shadow_cont(c->cus * c->occ_shadow, st, c->S, L, level, lslots, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[0], c->d_tasks[1], 0u, 1u,
-                               c->task_cap, c->shadow_budget);
-            launch_shadow_cont(c->cus * c->occ_shadow, st, c->S, L, level, lslots, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[1], nullptr, 1u, 0u,
+                      c->d_tasks[0], c->task_cap, c->shadow_budget, c->task_target);
+        if (!c->flat && !count && c->shadow_budget != 0u)      // the big leaves of the shadow units, spread over all waves
+            launch_shadow_cont(c->cus * c->occ_shadow, st, c->S, L, level, lslots, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[0], nullptr, 2u, 0u,
                                c->task_cap, 0u);
-        }
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));   // after the whole shadow group (incl. continuations)
         launch_shade(c->cus * c->occ_shade, st, c->S, L, F, level, 3 * level + 2, lslots, c->d_items, c->d_ctl, c->d_vis, rec_l, fres_l, c->d_rays[(level + 1) & 1]);
         if (timed == 1) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
@@ -553,7 +588,7 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
     HIPCHK(c, hipStreamSynchronize(st));
     Control h;
     HIPCHK(c, hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
-    if (std::getenv("RT_DEBUG")) std::fprintf(stderr, "RT_DEBUG level0: items %u tasks q0 %u q1 %u\n", h.n_items[0], h.n_tasks[0][0], h.n_tasks[0][1]);
+    if (std::getenv("RT_DEBUG")) std::fprintf(stderr, "RT_DEBUG level0: items %u tasks closest %u %u centre %u %u shadow %u %u\n", h.n_items[0], h.n_tasks[0][0], 0u, h.n_tasks[0][1], 0u, h.n_tasks[0][2], 0u);
     out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample;
     out->pixels = F.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;
 #ifdef RT_PROFILE
@@ -562,6 +597,11 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
                      h.prof[0], h.prof[1], h.prof[2], h.prof[3], h.prof[4], h.prof[5], h.prof[6], h.prof[7], h.prof[8], h.prof[14], h.prof[12], h.prof[13]);
         std::fprintf(stderr, "RT_PROFILE shadow units %llu: cycles max %llu mean %.0f; log2 histogram:", h.prof[11], h.prof[9], h.prof[11] ? double(h.prof[10]) / double(h.prof[11]) : 0.0);
         for (int b = 8; b <= 30; ++b) std::fprintf(stderr, " [2^%d]=%llu", b, h.prof[16 + b]);
+        std::fprintf(stderr, "\n");
+        std::fprintf(stderr, "RT_PROFILE slowest trace tile %llu: ray-mode leaf triangles %llu, tri-mode leaf triangles %llu, tri-mode (ray,chunk) tests %llu, child boxes %llu\n",
+                     h.prof[56], h.prof[57], h.prof[58], h.prof[59], h.prof[60]);
+        std::fprintf(stderr, "RT_PROFILE trace tiles: cycles max %llu sum %llu; log2 histogram:", h.prof[38], h.prof[39]);
+        for (int b = 8; b <= 23; ++b) std::fprintf(stderr, " [2^%d]=%llu", b, h.prof[40 + b]);
         std::fprintf(stderr, "\n");
     }
 #endif
@@ -670,7 +710,8 @@ extern "C" rt_status rt_graph_create(rt_ctx *c, const rt_lights *lights, const r
     if (F.npix == 0) { c->err = "rt_graph_create: empty shard"; return RT_ERR_INVALID; }
     // every allocation happens BEFORE the capture
     const size_t P = (static_cast<size_t>(L.n_samples) + 63) / 64;
-    if ((s = ensure_frame(c, F.npix, F.max_depth + 1, static_cast<size_t>(F.npix) * L.n_lights * P)) != RT_OK) return s;
+    if ((s = ensure_frame(c, F.npix, F.max_depth + 1, static_cast<size_t>(F.npix) * L.n_lights * P,
+                          std::max(static_cast<size_t>(F.tiles_x) * static_cast<size_t>(F.tiles_y), static_cast<size_t>(F.npix) / 64 + 1), static_cast<size_t>(L.n_lights))) != RT_OK) return s;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     rt_graph *g = new rt_graph();
     g->ctx = c; g->F = F; g->generation = c->frame_generation;
@@ -789,7 +830,8 @@ extern "C" rt_status rt_trace_rays(rt_ctx *c, const rt_lights *lights, int32_t m
     F.max_depth = max_depth < 0 ? RT_MAX_DEPTH : max_depth;
     F.dyn_trace = c->dyn_trace;
     const size_t P = (static_cast<size_t>(L.n_samples) + 63) / 64;
-    if ((s = ensure_frame(c, F.npix, F.max_depth + 1, static_cast<size_t>(F.npix) * L.n_lights * P)) != RT_OK) return s;
+    if ((s = ensure_frame(c, F.npix, F.max_depth + 1, static_cast<size_t>(F.npix) * L.n_lights * P,
+                          std::max(static_cast<size_t>(F.tiles_x) * static_cast<size_t>(F.tiles_y), static_cast<size_t>(F.npix) / 64 + 1), static_cast<size_t>(L.n_lights))) != RT_OK) return s;
     std::vector<RayItem> rays(static_cast<size_t>(n));
     for (int32_t i = 0; i < n; ++i) {
         RayItem &r = rays[static_cast<size_t>(i)];

@@ -71,14 +71,26 @@ struct alignas(16) ShadeItem {   // a lit closest hit waiting for its sample sha
 };
 static_assert(sizeof(ShadeItem) == 64, "ShadeItem must be 64 bytes");
 
-// A suspended piece of a shadow unit's traversal: the sub-tree under `node` for the rays in `mask` (lane mask of the
-// unit's wave).  Emitted when a unit exceeds its work budget, resumed by k_shadow_cont on whichever wave is free.
+// A piece of a unit's work handed to other waves: the chunks [c_begin, c_end) (64 triangles each) of leaf `node` for the
+// rays in `mask` (lane mask of the unit's wave).  Big leaves are never processed inline by the walking wave: one wave
+// grinding through a 979-triangle leaf for 64 rays was the critical path of whole kernels.
 struct alignas(16) ContTask {
     uint32_t unit;
     uint32_t node;
     unsigned long long mask;
+    uint32_t c_begin, c_end;
+    uint32_t pad0, pad1;
 };
-static_assert(sizeof(ContTask) == 16, "ContTask must be 16 bytes");
+static_assert(sizeof(ContTask) == 32, "ContTask must be 32 bytes");
+
+// queues of one traversal launch: where its continuation tasks come from / go to (indices into Control::n_tasks[level])
+struct TaskQueues {
+    const ContTask *tasks_in;     // continuation launches only
+    ContTask *tasks_out;          // nullptr: never hand work away
+    uint32_t q_in, q_out;
+    uint32_t cap, budget;         // queue capacity; leaves whose estimated cost (VALU instructions) exceeds `budget` are split into tasks (0 = off)
+    uint32_t target = 0;          // estimated cost of one task piece (0: same as budget)
+};
 
 // blend kinds stored in rec[].w (bit pattern of a uint32)
 enum : uint32_t {
@@ -137,7 +149,7 @@ struct Control {
     uint32_t queue[3 * (RT_MAX_DEPTH + 1) + 4][RT_QUEUE_SHARDS * 16];
     uint32_t n_items[RT_MAX_DEPTH + 1];              // lit hits per level
     uint32_t n_rays[RT_MAX_DEPTH + 2];               // bounce rays per level (n_rays[0] = rt_trace_rays input count)
-    uint32_t n_tasks[RT_MAX_DEPTH + 1][2];           // continuation tasks per level and queue
+    uint32_t n_tasks[RT_MAX_DEPTH + 1][4];           // leaf tasks per level: closest q0 | centre q1 | shadow q2 | (spare)
     unsigned long long rays_primary, rays_bounce, rays_centre, rays_sample, pixels_culled, shaded_hits;
     unsigned long long box_tests, leaf_tri_refs;              // k_trace (closest hit + light-centre rays)
     unsigned long long box_tests_shadow, leaf_tri_refs_shadow; // k_shadow (area-light sample rays)

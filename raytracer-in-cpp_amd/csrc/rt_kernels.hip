@@ -166,6 +166,12 @@ struct WaveStack {
     unsigned long long *mask;
     uint4 *stage;            // per-wave LDS staging buffer: RT_STAGE_TRIS leaf-triangle records (80 B each)
 };
+#ifdef RT_PROFILE
+__device__ uint32_t g_wave_steps[4];     // diagnostic: written by the wave that holds the slowest tile (racy by design)
+#define RT_TILE_COUNT(stk, lane, idx, val) do { if ((lane) == 0) (stk).node[RT_STACK - 4 + (idx)] += (val); } while (0)
+#else
+#define RT_TILE_COUNT(stk, lane, idx, val) do { } while (0)
+#endif
 #define RT_STAGE_TRIS 64
 #define RT_SCALAR_LEAF_MAX 16   // leaves up to this size are walked with scalar loads straight from the scalar cache
 
@@ -202,17 +208,18 @@ __device__ __forceinline__ TriRec tri_load_uniform(const TriRec *p) {
 
 // How a packet walk starts and when it gives work away.
 struct WalkCtl {
-    bool resume;                      // start from (start_node, start_mask) instead of the root
+    bool resume;                      // leaf task: process chunks [c_begin, c_end) of leaf `start_node` for `start_mask`, nothing else
     uint32_t start_node;
     unsigned long long start_mask;
-    uint32_t budget;                  // 0 = never flush; otherwise: estimated VALU instructions a unit may spend before its
-                                      // remaining stack entries are turned into continuation tasks
+    uint32_t c_begin, c_end;
+    uint32_t budget;                  // 0 = process every leaf inline; otherwise leaves whose estimated cost exceeds it become tasks
     uint32_t unit;                    // unit id stored in the emitted tasks
     ContTask *tasks;                  // output queue (capacity task_cap) and its counter
     uint32_t *task_count;
+    uint32_t target;                  // estimated cost of one task piece
     uint32_t task_cap;
 };
-__device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, nullptr, nullptr, 0u}; }
+__device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, 0u, 0u, nullptr, nullptr, 1u, 0u}; }
 
 __device__ __forceinline__ TriRec tri_from_regs(const u32x16 &lo, const u32x4 &hi) {
     TriRec t;
@@ -271,7 +278,6 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                                             float &best_t, int &best_f, bool &occluded,
                                             uint32_t &cnt_box, uint32_t &cnt_ref) {
     int sp = 0;
-    uint32_t spent = 0, budget = wc.budget;
     {
         unsigned long long m0 = __ballot(in_root);
         if (wc.resume) m0 &= wc.start_mask;
@@ -282,24 +288,6 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
         sp = 1;
     }
     while (sp > 0) {
-        if (budget != 0u && spent > budget) {
-            // Over budget: hand the remaining sub-trees to other waves.  One atomic reserves `sp` slots; if the queue
-            // is full the reservation is undone and the unit simply finishes here.
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(wc.task_count, static_cast<uint32_t>(sp));
-            base = uniform_u32(base);
-            if (base + static_cast<uint32_t>(sp) <= wc.task_cap) {
-                __builtin_amdgcn_wave_barrier();
-                for (int i = lane; i < sp; i += 64) {
-                    ContTask t;
-                    t.unit = wc.unit; t.node = stk.node[i]; t.mask = stk.mask[i];
-                    wc.tasks[base + static_cast<uint32_t>(i)] = t;
-                }
-                return;
-            }
-            if (lane == 0) atomicSub(wc.task_count, static_cast<uint32_t>(sp));
-            budget = 0u;
-        }
         --sp;
         __builtin_amdgcn_wave_barrier();
         const uint32_t ni = uniform_u32(stk.node[sp]);
@@ -317,9 +305,33 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
             // lanes=triangles estimate: one bound test per chunk + live rays x the share of chunks a ray cannot skip
             const bool tri_mode = nchunk * RT_COST_CHUNK_TEST + static_cast<uint32_t>(__popcll(live)) * ((nchunk + 2u) / 3u) * RT_COST_TRI_MODE
                                   < cnt * RT_COST_RAY_MODE;
-            spent += tri_mode ? nchunk * RT_COST_CHUNK_TEST + static_cast<uint32_t>(__popcll(live)) * ((nchunk + 2u) / 3u) * RT_COST_TRI_MODE
-                              : cnt * RT_COST_RAY_MODE;
+            const uint32_t est = tri_mode ? nchunk * RT_COST_CHUNK_TEST + static_cast<uint32_t>(__popcll(live)) * ((nchunk + 2u) / 3u) * RT_COST_TRI_MODE
+                                          : cnt * RT_COST_RAY_MODE;
+            uint32_t cb = 0u, ce = nchunk;                       // chunk range processed here
+            if (wc.resume) {
+                cb = wc.c_begin; ce = wc.c_end < nchunk ? wc.c_end : nchunk;
+            } else if (wc.budget != 0u && est > wc.budget) {
+                // hand the leaf away as ~target-instruction pieces (whole chunks); one atomic reserves the slots
+                uint32_t ntask = (est + wc.target - 1u) / wc.target;
+                if (ntask > nchunk) ntask = nchunk;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(wc.task_count, ntask);
+                base = uniform_u32(base);
+                if (base + ntask <= wc.task_cap) {
+                    for (uint32_t i = static_cast<uint32_t>(lane); i < ntask; i += 64u) {
+                        ContTask t;
+                        t.unit = wc.unit; t.node = ni; t.mask = live;
+                        t.c_begin = static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * i / ntask);
+                        t.c_end = static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * (i + 1u) / ntask);
+                        t.pad0 = t.pad1 = 0u;
+                        wc.tasks[base + i] = t;
+                    }
+                    continue;
+                }
+                if (lane == 0) atomicSub(wc.task_count, ntask);   // queue full: process inline
+            }
             RT_PROF_ADD(lane, tri_mode ? 7 : 6, 1);
+            RT_TILE_COUNT(stk, lane, tri_mode ? 1 : 0, cnt);
             if (tri_mode) {
                 RT_PROF_ADD(lane, 8, __popcll(live));
                 // ---- lanes = triangles.  Each lane keeps ONE leaf triangle in registers (coalesced 80-B records, next
@@ -337,8 +349,9 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                 const float idy_ = fabsf(dy) > 1e-30f ? 1.0f / dy : copysignf(1e30f, dy);
                 const float idz_ = fabsf(dz) > 1e-30f ? 1.0f / dz : copysignf(1e30f, dz);
                 const float slab_pad = 4e-4f * (fabsf(ox) + fabsf(oy) + fabsf(oz) + extent);
-                TriRec tr = T[static_cast<uint32_t>(lane) < cnt ? static_cast<uint32_t>(lane) : 0u];
-                for (uint32_t c0 = 0; c0 < cnt; c0 += 64u) {
+                const uint32_t t_end = ce * 64u < cnt ? ce * 64u : cnt;
+                TriRec tr = T[cb * 64u + static_cast<uint32_t>(lane) < cnt ? cb * 64u + static_cast<uint32_t>(lane) : 0u];
+                for (uint32_t c0 = cb * 64u; c0 < t_end; c0 += 64u) {
                     const uint32_t n = cnt - c0 < 64u ? cnt - c0 : 64u;
                     const bool has = static_cast<uint32_t>(lane) < n && !(ANY && (tr.flags & 1u));
                     const uint32_t nx = c0 + 64u + static_cast<uint32_t>(lane);
@@ -347,15 +360,15 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                     // which of those are also outside the chunk's normal cone band (then no plane of the chunk is near-parallel)
                     unsigned long long todo = live, guard_rays = 0ull;
                     {
-                        const ChunkBound cb = cbounds[c0 >> 6];
-                        if (cb.sin_guard < 1.5f) {
-                            const float t0x = (cb.lo[0] - slab_pad - ox) * idx_, t1x = (cb.hi[0] + slab_pad - ox) * idx_;
-                            const float t0y = (cb.lo[1] - slab_pad - oy) * idy_, t1y = (cb.hi[1] + slab_pad - oy) * idy_;
-                            const float t0z = (cb.lo[2] - slab_pad - oz) * idz_, t1z = (cb.hi[2] + slab_pad - oz) * idz_;
+                        const ChunkBound bd = cbounds[c0 >> 6];
+                        if (bd.sin_guard < 1.5f) {
+                            const float t0x = (bd.lo[0] - slab_pad - ox) * idx_, t1x = (bd.hi[0] + slab_pad - ox) * idx_;
+                            const float t0y = (bd.lo[1] - slab_pad - oy) * idy_, t1y = (bd.hi[1] + slab_pad - oy) * idy_;
+                            const float t0z = (bd.lo[2] - slab_pad - oz) * idz_, t1z = (bd.hi[2] + slab_pad - oz) * idz_;
                             const float tin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
                             const float tout = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
                             const bool miss = tin > tout;
-                            const bool cone_safe = fabsf(dx * cb.ax + dy * cb.ay + dz * cb.az) > cb.pad0 * d_len;
+                            const bool cone_safe = fabsf(dx * bd.ax + dy * bd.ay + dz * bd.az) > bd.pad0 * d_len;
                             const unsigned long long boxmiss = __ballot(miss) & live;
                             const unsigned long long culled = __ballot(miss && cone_safe) & live;
                             todo = live & ~culled;
@@ -382,6 +395,7 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                         const int r1 = two ? static_cast<int>(__builtin_ctzll(todo)) : r0;
                         if (two) todo &= todo - 1ull;
                         RT_PROF_ADD(lane, 2, two ? 2 : 1); RT_PROF_ADD(lane, 3, (two ? 2 : 1) * __popcll(__ballot(has)));
+                        RT_TILE_COUNT(stk, lane, 2, two ? 2 : 1);
                         // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 (same operations as the ray-lane form)
                         float tq[2]; bool inq[2];
 #pragma unroll
@@ -467,7 +481,8 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                         test_lane(tri_load_uniform(T + k));
                     }
                 } else {
-                    for (uint32_t c0 = 0; c0 < cnt; c0 += RT_STAGE_TRIS) {
+                    const uint32_t r_end = ce * 64u < cnt ? ce * 64u : cnt;
+                    for (uint32_t c0 = cb * 64u; c0 < r_end; c0 += RT_STAGE_TRIS) {
                         const uint32_t n = cnt - c0 < RT_STAGE_TRIS ? cnt - c0 : RT_STAGE_TRIS;
                         const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(T + c0);
                         __builtin_amdgcn_wave_barrier();
@@ -493,7 +508,7 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                 }
             }
         } else {
-            spent += cnt * 35u;
+            RT_TILE_COUNT(stk, lane, 3, cnt);
             for (uint32_t c = 0; c < cnt; ++c) {
                 const uint32_t ci = nd.first + c;
                 const rt_node ch = nodes[ci];
@@ -617,7 +632,10 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
     if (F.dyn_trace) q.init(ctl->queue[ctr_slot], ntiles, gridDim.x * RT_WAVES, blockIdx.x, lane);
     else q.init_static(ntiles, gridDim.x * RT_WAVES, uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave)), lane);
     for (uint32_t tile = 0; q.next(tile);) {
-
+#ifdef RT_PROFILE
+        const long long prof_t0 = clock64();
+        if (lane == 0) { stk.node[RT_STACK - 4] = 0; stk.node[RT_STACK - 3] = 0; stk.node[RT_STACK - 2] = 0; stk.node[RT_STACK - 1] = 0; }
+#endif
         bool valid;
         uint32_t pix = 0, lmode = 0;
         float ox, oy, oz, dx, dy, dz, lx = 0.f, ly = 0.f, lz = 0.f;
@@ -706,8 +724,226 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
                 items[base + lanes_below(lm)] = o;
             }
         }
+#ifdef RT_PROFILE
+        {   // per-tile cycle histogram of k_trace: prof[40 + log2(cycles)] (capped at 2^23), max prof[38], sum prof[39]
+            const unsigned long long dt = static_cast<unsigned long long>(clock64() - prof_t0);
+            if (lane == 0 && g_prof) {
+                if (atomicMax(&g_prof[38], dt) < dt) {      // new slowest tile: remember what it did
+                    g_prof[56] = tile; g_prof[57] = stk.node[RT_STACK - 4]; g_prof[58] = stk.node[RT_STACK - 3];
+                    g_prof[59] = stk.node[RT_STACK - 2]; g_prof[60] = stk.node[RT_STACK - 1];
+                }
+                atomicAdd(&g_prof[39], dt);
+                int b = 63 - __builtin_clzll(dt | 1ull); if (b > 23) b = 23;
+                atomicAdd(&g_prof[40 + b], 1ull);
+            }
+        }
+#endif
     }
     // per-wave counters -> control block
+    c_rays = wave_sum(c_rays); c_cull = wave_sum(c_cull); c_centre = wave_sum(c_centre);
+    if (COUNT) { c_box = wave_sum(c_box); c_ref = wave_sum(c_ref); }
+    if (lane == 0) {
+        if (c_rays) atomicAdd((PRIMARY || level == 0) ? &ctl->rays_primary : &ctl->rays_bounce, static_cast<unsigned long long>(c_rays));
+        if (c_cull) atomicAdd(&ctl->pixels_culled, static_cast<unsigned long long>(c_cull));
+        if (c_centre) atomicAdd(&ctl->rays_centre, static_cast<unsigned long long>(c_centre));
+        if (COUNT) {
+            if (c_box) atomicAdd(&ctl->box_tests, static_cast<unsigned long long>(c_box));
+            if (c_ref) atomicAdd(&ctl->leaf_tri_refs, static_cast<unsigned long long>(c_ref));
+        }
+    }
+}
+
+// ======================================================================================================
+// K1 for TREE scenes, split in three so that every traversal can hand work away (measured on dodgeColorTest: ONE 8x8 tile
+// cost 2.45 M cycles -- the whole fused kernel -- while the average wave had 0.18 M cycles of work):
+//   STAGE 0  closest hit        -> best[tile*64+lane] = (t bits << 32 | face), merged by continuations with atomicMin
+//                                  (minimum t, ties to the lowest face id: exactly the reference's strict '<' over the
+//                                  ascending std::set, flyscene.cpp:675-683)
+//   STAGE 1  light-centre rays  -> lit[tile*lslots+l] = lane mask of visible centres, continuations clear bits (atomicAnd)
+//   STAGE 2  finish             -> BACKGROUND / SHADOW records, out_hit/out_t, compaction of lit hits
+// The fused k_trace above remains the path of flat scenes (cube.obj).
+// ======================================================================================================
+
+struct TileRay {
+    bool valid, pre;
+    uint32_t pix, lmode;
+    float ox, oy, oz, dx, dy, dz, lx, ly, lz;
+};
+
+template <bool PRIMARY>
+__device__ __forceinline__ TileRay tile_ray(const uint32_t tile, const int lane, const DFrame &F, const DCam &cam, const rt_node &root,
+                                            const RayItem *__restrict__ rays_in, const uint32_t n_in) {
+    TileRay r;
+    r.lx = r.ly = r.lz = 0.f; r.lmode = 0u;
+    if (PRIMARY) {
+        const int tx = static_cast<int>(tile % static_cast<uint32_t>(F.tiles_x)), ty = static_cast<int>(tile / static_cast<uint32_t>(F.tiles_x));
+        const int x = tx * 8 + (lane & 7), lr = ty * 8 + (lane >> 3);
+        r.valid = (x < F.width) && (lr < F.local_rows);
+        const int y = F.row0 + ((lr / F.stripe) * F.nranks + F.rank) * F.stripe + (lr % F.stripe);
+        r.pix = static_cast<uint32_t>(lr) * static_cast<uint32_t>(F.width) + static_cast<uint32_t>(x);
+        // Camera::screenToWorld, camera.hpp:155-173 (see k_trace)
+        const float fi = static_cast<float>(x), fj = static_cast<float>(y);
+        float n0 = static_cast<float>(2.0 * static_cast<double>(fi - cam.vp[0]) / static_cast<double>(cam.vp[2]) - 1.0);
+        float n1 = static_cast<float>(1.0 - 2.0 * static_cast<double>(fj - cam.vp[1]) / static_cast<double>(cam.vp[3]));
+        const float n2 = -1.0f;
+        n0 = n0 * cam.k0;
+        n1 = n1 * cam.k1;
+        const float *m = cam.inv_view;
+        const float sx = ((m[0] * n0 + m[1] * n1) + m[2] * n2) + m[3] * 1.0f;
+        const float sy = ((m[4] * n0 + m[5] * n1) + m[6] * n2) + m[7] * 1.0f;
+        const float sz = ((m[8] * n0 + m[9] * n1) + m[10] * n2) + m[11] * 1.0f;
+        r.ox = cam.center[0]; r.oy = cam.center[1]; r.oz = cam.center[2];
+        r.dx = sx - r.ox; r.dy = sy - r.oy; r.dz = sz - r.oz;          // flyscene.cpp:619
+        r.pre = r.valid && box_hit_verified(root.bmin, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, __builtin_amdgcn_rcpf(r.dx),
+                                            __builtin_amdgcn_rcpf(r.dy), __builtin_amdgcn_rcpf(r.dz));                 // flyscene.cpp:576
+    } else {
+        const uint32_t k = tile * 64u + static_cast<uint32_t>(lane);
+        r.valid = k < n_in;
+        const RayItem it = rays_in[r.valid ? k : 0u];
+        r.ox = it.ox; r.oy = it.oy; r.oz = it.oz; r.dx = it.dx; r.dy = it.dy; r.dz = it.dz;
+        r.lx = it.lx; r.ly = it.ly; r.lz = it.lz; r.lmode = it.lmode; r.pix = it.pix;
+        r.pre = r.valid;
+    }
+    return r;
+}
+
+#define RT_NO_HIT_KEY 0xffffffffffffffffull
+
+template <bool PRIMARY, bool COUNT, int STAGE, bool CONT>
+__global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
+                                                          const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
+                                                          const DScene S, const DCam *__restrict__ camp, const DLights L, const DFrame F,
+                                                          const int level, const int lslots,
+                                                          const RayItem *__restrict__ rays_in, ShadeItem *__restrict__ items,
+                                                          Control *__restrict__ ctl, float4 *__restrict__ rec,
+                                                          int32_t *__restrict__ out_hit, float *__restrict__ out_t,
+                                                          unsigned long long *best, unsigned long long *lit, const TaskQueues Q) {
+    __shared__ uint4 s_stage[RT_WAVES * RT_STAGE_TRIS * 5];
+    __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
+    __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, s_stage + wave * RT_STAGE_TRIS * 5};
+    const uint32_t n_in = PRIMARY ? 0u : ctl->n_rays[level];
+    const uint32_t ntiles = PRIMARY ? static_cast<uint32_t>(F.tiles_x) * static_cast<uint32_t>(F.tiles_y) : (n_in + 63u) / 64u;
+    const rt_node root = nodes[0];
+    DCam cam;
+    if (PRIMARY) cam = *camp;
+
+    uint32_t n_units = STAGE == 1 ? ntiles * static_cast<uint32_t>(lslots) : ntiles;
+    if (CONT) {
+        n_units = ctl->n_tasks[level][Q.q_in];
+        if (n_units > Q.cap) n_units = Q.cap;
+    }
+    uint32_t c_rays = 0, c_cull = 0, c_centre = 0, c_box = 0, c_ref = 0;
+    ShardedQueue q;
+    q.init_static(n_units, gridDim.x * RT_WAVES, uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave)), lane);
+    for (uint32_t work = 0; q.next(work);) {
+        uint32_t unit = work;
+        WalkCtl wc = walk_plain();
+        if (CONT) {
+            const ContTask task = Q.tasks_in[work];
+            unit = uniform_u32(task.unit);
+            wc.resume = true;
+            wc.start_node = uniform_u32(task.node);
+            wc.start_mask = uniform_u64(task.mask);
+            wc.c_begin = uniform_u32(task.c_begin);
+            wc.c_end = uniform_u32(task.c_end);
+        }
+        if (STAGE < 2 && Q.tasks_out != nullptr && Q.budget != 0u) {
+            wc.budget = Q.budget; wc.unit = unit; wc.tasks = Q.tasks_out; wc.task_count = &ctl->n_tasks[level][Q.q_out]; wc.task_cap = Q.cap;
+            wc.target = Q.target ? Q.target : Q.budget;
+        }
+        const uint32_t tile = STAGE == 1 ? unit / static_cast<uint32_t>(lslots) : unit;
+        const int l = STAGE == 1 ? static_cast<int>(unit - tile * static_cast<uint32_t>(lslots)) : 0;
+        const TileRay r = tile_ray<PRIMARY>(tile, lane, F, cam, root, rays_in, n_in);
+        const size_t ray_slot = static_cast<size_t>(tile) * 64u + static_cast<size_t>(lane);
+
+        if (STAGE == 0) {
+            // ---- closest hit (flyscene.cpp:655-691)
+            bool in_root = r.pre;
+            const float bx = (r.ox + r.dx) - r.ox, by = (r.oy + r.dy) - r.oy, bz = (r.oz + r.dz) - r.oz;   // (o + d) - o, flyscene.cpp:655
+            const float brx = __builtin_amdgcn_rcpf(bx), bry = __builtin_amdgcn_rcpf(by), brz = __builtin_amdgcn_rcpf(bz);
+            if (!CONT) {
+                c_cull += (PRIMARY && r.valid && !r.pre) ? 1u : 0u;
+                c_rays += in_root ? 1u : 0u;
+                if (COUNT && in_root) c_box += 1;
+                in_root = in_root && box_hit_verified(root.bmin, r.ox, r.oy, r.oz, bx, by, bz, brx, bry, brz);
+            }
+            float best_t = 3.402823466e+38f;
+            int best_f = -1;
+            bool dummy = false;
+            packet_walk<false, COUNT>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, wc, in_root, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz,
+                                      bx, by, bz, brx, bry, brz, best_t, best_f, dummy, c_box, c_ref);
+            const bool found = best_f >= 0 && static_cast<uint32_t>(best_f) < S.n_faces;
+            const unsigned long long key = found ? ((static_cast<unsigned long long>(__float_as_uint(best_t)) << 32) | static_cast<uint32_t>(best_f))
+                                                 : RT_NO_HIT_KEY;
+            if (CONT) { if (found) atomicMin(&best[ray_slot], key); }
+            else best[ray_slot] = key;
+        } else {
+            const unsigned long long key = best[ray_slot];
+            const bool hit = r.valid && key != RT_NO_HIT_KEY;
+            const float best_t = __uint_as_float(static_cast<uint32_t>(key >> 32));
+            const int best_f = static_cast<int>(static_cast<uint32_t>(key));
+            const float hx = r.ox + best_t * r.dx, hy = r.oy + best_t * r.dy, hz = r.oz + best_t * r.dz;   // flyscene.cpp:695
+            const int nl_lane = r.lmode ? 1 : L.n_lights;
+            if (STAGE == 1) {
+                // ---- lightStrikes(hitPoint, lights): the segment to light CENTRE l (flyscene.cpp:700)
+                bool act = hit && (l < nl_lane);
+                const unsigned long long lit_index = static_cast<unsigned long long>(tile) * static_cast<unsigned long long>(lslots) + static_cast<unsigned long long>(l);
+                if (CONT) act = act && (((lit[lit_index] >> lane) & 1ull) != 0ull);     // still believed visible
+                if (__ballot(act) == 0ull) {
+                    if (!CONT && lane == 0) lit[lit_index] = 0ull;
+                    continue;
+                }
+                const float px = r.lmode ? r.lx : L.pos[l][0], py = r.lmode ? r.ly : L.pos[l][1], pz = r.lmode ? r.lz : L.pos[l][2];
+                const float sdx = hx - px, sdy = hy - py, sdz = hz - pz;
+                const float srx = __builtin_amdgcn_rcpf(sdx), sry = __builtin_amdgcn_rcpf(sdy), srz = __builtin_amdgcn_rcpf(sdz);
+                bool sroot = act;
+                if (!CONT) {
+                    c_centre += act ? 1u : 0u;
+                    if (COUNT && act) c_box += 1;
+                    sroot = act && box_hit_verified(root.bmin, px, py, pz, sdx, sdy, sdz, srx, sry, srz);
+                }
+                float t_unused = 0.f; int f_unused = -1;
+                bool occ = false;
+                packet_walk<true, COUNT>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, wc, sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz,
+                                         srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref);
+                if (CONT) {
+                    const unsigned long long om = __ballot(act && occ);
+                    if (lane == 0 && om != 0ull) atomicAnd(&lit[lit_index], ~om);
+                } else {
+                    const unsigned long long vm = __ballot(act && !occ);
+                    if (lane == 0) lit[lit_index] = vm;
+                }
+            } else {
+                // ---- finish: classification, outputs, compaction of lit hits (wave ballot + prefix, one atomic per wave)
+                bool is_lit = false;
+                for (int k = 0; k < lslots; ++k) {
+                    const unsigned long long w = lit[static_cast<unsigned long long>(tile) * static_cast<unsigned long long>(lslots) + static_cast<unsigned long long>(k)];
+                    is_lit = is_lit || (hit && k < nl_lane && ((w >> lane) & 1ull) != 0ull);
+                }
+                if (r.valid) {
+                    if (!hit) rec[r.pix] = make_float4(1.f, 1.f, 1.f, __uint_as_float(KIND_CONST));          // BACKGROUND
+                    else if (!is_lit) rec[r.pix] = make_float4(0.f, 0.f, 0.f, __uint_as_float(KIND_CONST)); // SHADOW
+                    if (out_hit) out_hit[r.pix] = hit ? best_f : -1;
+                    if (out_t) out_t[r.pix] = hit ? best_t : -1.0f;
+                }
+                const unsigned long long lm = __ballot(is_lit);
+                if (lm != 0ull) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&ctl->n_items[level], static_cast<uint32_t>(__popcll(lm)));
+                    base = uniform_u32(base);
+                    if (is_lit) {
+                        ShadeItem o;
+                        o.ox = r.ox; o.oy = r.oy; o.oz = r.oz; o.dx = r.dx; o.dy = r.dy; o.dz = r.dz;
+                        o.lx = r.lx; o.ly = r.ly; o.lz = r.lz; o.lmode = r.lmode; o.pix = r.pix; o.face = best_f; o.t = best_t;
+                        o.pad0 = o.pad1 = o.pad2 = 0u;
+                        items[base + lanes_below(lm)] = o;
+                    }
+                }
+            }
+        }
+    }
     c_rays = wave_sum(c_rays); c_cull = wave_sum(c_cull); c_centre = wave_sum(c_centre);
     if (COUNT) { c_box = wave_sum(c_box); c_ref = wave_sum(c_ref); }
     if (lane == 0) {
@@ -726,23 +962,17 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
 // One wave = the N samples of one (hit, light) pair (N = 64), several pairs per wave (N < 64) or
 // ceil(N/64) wave passes per pair (N > 64).  Output: one visibility bit per sample.
 // ======================================================================================================
-// Work-budget continuation (tree scenes): a unit whose estimated work exceeds `budget` turns the rest of its traversal
-// stack into ContTask records (node, lane mask) in `tasks_out`; k_shadow<.., CONT=true> resumes those sub-trees on
-// whichever wave is free and merges the occluded bits into `vis` with atomicAnd.  Measured need: on dodgeColorTest a
-// few units cost 40x the mean and waves were resident for only 50 % of the kernel.
-struct ShadowQueues {
-    const ContTask *tasks_in;     // CONT only
-    ContTask *tasks_out;          // nullptr: never flush
-    uint32_t q_in, q_out;         // indices into Control::n_tasks[level]
-    uint32_t cap, budget;
-};
+// Leaf tasks (tree scenes): leaves whose estimated cost exceeds `budget` are not processed by the walking wave but written
+// to `tasks_out` as chunk-range pieces; k_shadow<.., CONT=true> processes them on whichever wave is free and merges the
+// occluded bits into `vis` with atomicAnd.  (A first version handed over whole sub-trees once a unit was over budget: the
+// pieces were still 979-triangle leaves and the passes ran back to back -- no gain.)
 
 template <bool COUNT, bool FLAT, bool CONT>
 __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
                                                           const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                                            const DScene S, const DLights L, const int level, const int ctr_slot,
                                                            const int lslots, const ShadeItem *__restrict__ items,
-                                                           Control *__restrict__ ctl, unsigned long long *vis, const ShadowQueues Q) {
+                                                           Control *__restrict__ ctl, unsigned long long *vis, const TaskQueues Q) {
     __shared__ uint4 s_stage[RT_WAVES * RT_STAGE_TRIS * 5];
     __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
     __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
@@ -782,9 +1012,12 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restr
             wc.resume = true;
             wc.start_node = uniform_u32(task.node);
             wc.start_mask = uniform_u64(task.mask);
+            wc.c_begin = uniform_u32(task.c_begin);
+            wc.c_end = uniform_u32(task.c_end);
         }
         if (!FLAT && Q.tasks_out != nullptr && Q.budget != 0u) {
             wc.budget = Q.budget; wc.unit = unit; wc.tasks = Q.tasks_out; wc.task_count = &ctl->n_tasks[level][Q.q_out]; wc.task_cap = Q.cap;
+            wc.target = Q.target ? Q.target : Q.budget;
         }
         uint32_t g, s, pass = 0;
         bool valid;
@@ -1123,8 +1356,8 @@ void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow
         *trace_rays = q(k_trace<false, false, true>, RT_WAVES * 64, 4);
         *shadow = q(k_shadow<false, true, false>, RT_WAVES * 64, 4);
     } else {
-        *trace_primary = q(k_trace<true, false, false>, RT_WAVES * 64, 4);
-        *trace_rays = q(k_trace<false, false, false>, RT_WAVES * 64, 4);
+        *trace_primary = q(k_stage<true, false, 0, false>, RT_WAVES * 64, 4);
+        *trace_rays = q(k_stage<false, false, 0, false>, RT_WAVES * 64, 4);
         *shadow = q(k_shadow<false, false, false>, RT_WAVES * 64, 4);
     }
     *shade = q(k_shade, 256, 2);
@@ -1137,35 +1370,58 @@ void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow
 void launch_trace(bool primary, bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DCam *camp, const DLights &L, const DFrame &Fr,
                   int level, int slot, const RayItem *rays_in, ShadeItem *items, Control *ctl, float4 *rec, int32_t *out_hit, float *out_t) {
     const dim3 g(grid), b(RT_WAVES * 64);
-    const int sel = (primary ? 4 : 0) | (count ? 2 : 0) | (flat ? 1 : 0);
+    if (flat) {
+        if (primary) { if (count) RT_LAUNCH_TRACE(true, true, true); else RT_LAUNCH_TRACE(true, false, true); }
+        else { if (count) RT_LAUNCH_TRACE(false, true, true); else RT_LAUNCH_TRACE(false, false, true); }
+    } else {               // fused kernel on a tree scene (the staged k_stage pipeline is the alternative)
+        if (primary) { if (count) RT_LAUNCH_TRACE(true, true, false); else RT_LAUNCH_TRACE(true, false, false); }
+        else { if (count) RT_LAUNCH_TRACE(false, true, false); else RT_LAUNCH_TRACE(false, false, false); }
+    }
+}
+
+#define RT_LAUNCH_STAGE(P, C, ST, K) hipLaunchKernelGGL((k_stage<P, C, ST, K>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, camp, L, Fr, level, lslots, rays_in, items, ctl, rec, out_hit, out_t, best, lit, Q)
+void launch_stage(bool primary, bool count, int stage, bool cont, int grid, hipStream_t st, const DScene &S, const DCam *camp, const DLights &L,
+                  const DFrame &Fr, int level, int lslots, const RayItem *rays_in, ShadeItem *items, Control *ctl, float4 *rec, int32_t *out_hit,
+                  float *out_t, unsigned long long *best, unsigned long long *lit, const TaskQueues &Q) {
+    const dim3 g(grid), b(RT_WAVES * 64);
+    if (cont) {            // continuations exist for the two traversal stages of the fast (non-counting) variants only
+        if (primary) { if (stage == 0) RT_LAUNCH_STAGE(true, false, 0, true); else RT_LAUNCH_STAGE(true, false, 1, true); }
+        else { if (stage == 0) RT_LAUNCH_STAGE(false, false, 0, true); else RT_LAUNCH_STAGE(false, false, 1, true); }
+        return;
+    }
+    const int sel = (primary ? 6 : 0) + (count ? 3 : 0) + stage;
     switch (sel) {
-        case 0: RT_LAUNCH_TRACE(false, false, false); break;
-        case 1: RT_LAUNCH_TRACE(false, false, true); break;
-        case 2: RT_LAUNCH_TRACE(false, true, false); break;
-        case 3: RT_LAUNCH_TRACE(false, true, true); break;
-        case 4: RT_LAUNCH_TRACE(true, false, false); break;
-        case 5: RT_LAUNCH_TRACE(true, false, true); break;
-        case 6: RT_LAUNCH_TRACE(true, true, false); break;
-        default: RT_LAUNCH_TRACE(true, true, true); break;
+        case 0: RT_LAUNCH_STAGE(false, false, 0, false); break;
+        case 1: RT_LAUNCH_STAGE(false, false, 1, false); break;
+        case 2: RT_LAUNCH_STAGE(false, false, 2, false); break;
+        case 3: RT_LAUNCH_STAGE(false, true, 0, false); break;
+        case 4: RT_LAUNCH_STAGE(false, true, 1, false); break;
+        case 5: RT_LAUNCH_STAGE(false, true, 2, false); break;
+        case 6: RT_LAUNCH_STAGE(true, false, 0, false); break;
+        case 7: RT_LAUNCH_STAGE(true, false, 1, false); break;
+        case 8: RT_LAUNCH_STAGE(true, false, 2, false); break;
+        case 9: RT_LAUNCH_STAGE(true, true, 0, false); break;
+        case 10: RT_LAUNCH_STAGE(true, true, 1, false); break;
+        default: RT_LAUNCH_STAGE(true, true, 2, false); break;
     }
 }
 
 #define RT_LAUNCH_SHADOW(C, F, K) hipLaunchKernelGGL((k_shadow<C, F, K>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, L, level, slot, lslots, items, ctl, vis, Q)
 void launch_shadow(bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
-                   const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget) {
+                   const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target) {
     const dim3 g(grid), b(RT_WAVES * 64);
-    const ShadowQueues Q{nullptr, (flat || count) ? nullptr : tasks_out, 0u, 0u, cap, (flat || count) ? 0u : budget};
+    const TaskQueues Q{nullptr, (flat || count) ? nullptr : tasks_out, 0u, 2u, cap, (flat || count) ? 0u : budget, target};
     if (count) { if (flat) RT_LAUNCH_SHADOW(true, true, false); else RT_LAUNCH_SHADOW(true, false, false); }
     else { if (flat) RT_LAUNCH_SHADOW(false, true, false); else RT_LAUNCH_SHADOW(false, false, false); }
 }
 
-// resumes the tasks of queue q_in; a unit that is still over budget flushes into queue q_out (tasks_out == nullptr: finishes)
+// processes the leaf tasks of queue q_in (leaf tasks never create new tasks)
 void launch_shadow_cont(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, const ShadeItem *items,
                         Control *ctl, unsigned long long *vis, const ContTask *tasks_in, ContTask *tasks_out, uint32_t q_in, uint32_t q_out,
                         uint32_t cap, uint32_t budget) {
     const dim3 g(grid), b(RT_WAVES * 64);
     const int slot = 0;
-    const ShadowQueues Q{tasks_in, tasks_out, q_in, q_out, cap, tasks_out ? budget : 0u};
+    const TaskQueues Q{tasks_in, tasks_out, q_in, q_out, cap, tasks_out ? budget : 0u};
     RT_LAUNCH_SHADOW(false, false, true);
 }
 
