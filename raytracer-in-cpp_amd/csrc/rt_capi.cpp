@@ -424,6 +424,7 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     std::memcpy(c->S.model, sc->model, sizeof(float) * 12);
     c->S.n_nodes = sc->n_nodes;
     c->S.n_faces = sc->n_faces;
+    c->S.plane_cull = (no_cull || std::getenv("RT_NO_PLANE_CULL") != nullptr) ? 0 : 1;
     c->flat = (sc->nodes[0].count_flags & RT_NODE_LEAF) && (sc->nodes[0].count_flags & 0x7fffffffu) <= 64u;
     query_occupancy(c->flat, &c->occ_trace_primary, &c->occ_trace_rays, &c->occ_shadow, &c->occ_shade);
     // k_trace uses static tile striding: with more than ~4 blocks/CU a wave owns so few tiles (32,400 tiles at 1080p)
@@ -588,6 +589,7 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
     HIPCHK(c, hipStreamSynchronize(st));
     Control h;
     HIPCHK(c, hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
+    fold_stats(h);
     if (std::getenv("RT_DEBUG")) std::fprintf(stderr, "RT_DEBUG level0: items %u tasks closest %u %u centre %u %u shadow %u %u\n", h.n_items[0], h.n_tasks[0][0], 0u, h.n_tasks[0][1], 0u, h.n_tasks[0][2], 0u);
     out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample;
     out->pixels = F.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;
@@ -776,6 +778,7 @@ extern "C" rt_status rt_timing_collect(rt_ctx *c, rt_stats *out) {
     HIPCHK(c, hipStreamSynchronize(c->pending_stream));
     Control h;
     HIPCHK(c, hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
+    fold_stats(h);
     out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample;
     out->pixels = c->pending_frame.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;
     rt_status s = RT_OK;

@@ -115,6 +115,7 @@ struct DScene {
     const rt_material *mats;
     float model[12];
     uint32_t n_nodes, n_faces;
+    int32_t plane_cull;                // k_shadow: per-unit plane culling (rt_kernels.hip, SegPacket); RT_NO_PLANE_CULL=1 turns it off
 };
 
 struct DCam {
@@ -142,6 +143,9 @@ struct DFrame {              // which pixels this launch covers
 };
 
 #define RT_QUEUE_SHARDS 8
+#define RT_STAT_SHARDS 64
+enum : int { ST_RAYS_PRIMARY = 0, ST_RAYS_BOUNCE, ST_RAYS_CENTRE, ST_RAYS_SAMPLE, ST_PIXELS_CULLED, ST_SHADED_HITS,
+             ST_BOX_TESTS, ST_LEAF_TRI_REFS, ST_BOX_TESTS_SHADOW, ST_LEAF_TRI_REFS_SHADOW };
 
 // control block in device memory (zeroed once per frame by a memset node on the render stream)
 struct Control {
@@ -150,11 +154,26 @@ struct Control {
     uint32_t n_items[RT_MAX_DEPTH + 1];              // lit hits per level
     uint32_t n_rays[RT_MAX_DEPTH + 2];               // bounce rays per level (n_rays[0] = rt_trace_rays input count)
     uint32_t n_tasks[RT_MAX_DEPTH + 1][4];           // leaf tasks per level: closest q0 | centre q1 | shadow q2 | (spare)
+    // totals, filled on the HOST by fold_stats() from the sharded counters below
     unsigned long long rays_primary, rays_bounce, rays_centre, rays_sample, pixels_culled, shaded_hits;
     unsigned long long box_tests, leaf_tri_refs;              // k_trace (closest hit + light-centre rays)
     unsigned long long box_tests_shadow, leaf_tri_refs_shadow; // k_shadow (area-light sample rays)
+    // what the kernels add to: one 128-byte line per shard, shard = blockIdx.x % RT_STAT_SHARDS.  (4096 waves adding
+    // to ONE line at kernel end serialise in the memory-side atomic unit: measured 176 us for the 1080p primary k_trace
+    // whose arithmetic needs < 20 us.)
+    unsigned long long stat[RT_STAT_SHARDS][16];
     // -DRT_PROFILE builds only: executed work (wave steps) and useful lane work per leaf mode / box tests
     unsigned long long prof[64];
 };
+
+inline void fold_stats(Control &h) {
+    unsigned long long t[16] = {0};
+    for (int sh = 0; sh < RT_STAT_SHARDS; ++sh)
+        for (int k = 0; k < 16; ++k) t[k] += h.stat[sh][k];
+    h.rays_primary = t[ST_RAYS_PRIMARY]; h.rays_bounce = t[ST_RAYS_BOUNCE]; h.rays_centre = t[ST_RAYS_CENTRE]; h.rays_sample = t[ST_RAYS_SAMPLE];
+    h.pixels_culled = t[ST_PIXELS_CULLED]; h.shaded_hits = t[ST_SHADED_HITS];
+    h.box_tests = t[ST_BOX_TESTS]; h.leaf_tri_refs = t[ST_LEAF_TRI_REFS];
+    h.box_tests_shadow = t[ST_BOX_TESTS_SHADOW]; h.leaf_tri_refs_shadow = t[ST_LEAF_TRI_REFS_SHADOW];
+}
 
 }  // namespace rtamd

@@ -206,6 +206,42 @@ __device__ __forceinline__ TriRec tri_load_uniform(const TriRec *p) {
     return t;
 }
 
+// Plane culling for shadow units.  All 64 segments of a k_shadow unit end at the same point h (the shaded hit) and start
+// at light samples inside the box [slo, shi].  Flyscene::rayTriangleIntersection (flyscene.cpp:787-819) accepts a triangle
+// only for 0.00001 < t, and lightStrikes (flyscene.cpp:874-899) only counts t < 0.98, with
+//      t = num / dn,   num = n.A - s.n,   dn = (h - s).n          (float, Eigen order)
+// so a triangle is irrelevant for EVERY segment of the unit when interval arithmetic over the sample box proves
+//   (A) num and dn have opposite signs (t <= 0: the plane lies behind the light sample), or
+//   (B) |num| >= 0.981 |dn| (|t| >= 0.98: the plane is not crossed before the hit point -- this covers the face h lies on).
+// Only signs and magnitudes of the reference's own two dot products are used, each bounded with a margin M = 2e-5 x the
+// operand magnitudes (>= 20x the worst-case float rounding of the reference's evaluation and of the interval arithmetic),
+// so the decision never depends on how accurate t is; a NaN anywhere makes every comparison false (= keep).
+struct SegPacket {
+    bool on;
+    float hx, hy, hz;              // common end point
+    float slx, sly, slz, shx, shy, shz;   // box of the start points (exact extreme samples)
+    float m0;                      // 2e-5 * (|slo|_1 + |shi|_1 + |h|_1)
+};
+__device__ __forceinline__ SegPacket seg_off() { return SegPacket{false, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
+
+__device__ __forceinline__ bool plane_rules_out(const SegPacket &g, const float nx, const float ny, const float nz, const float nA) {
+    const float ax = nx * g.slx, bx = nx * g.shx, ay = ny * g.sly, by = ny * g.shy, az = nz * g.slz, bz = nz * g.shz;
+    const float sn_lo = fminf(ax, bx) + (fminf(ay, by) + fminf(az, bz));
+    const float sn_hi = fmaxf(ax, bx) + (fmaxf(ay, by) + fmaxf(az, bz));
+    const float num_lo = nA - sn_hi, num_hi = nA - sn_lo;
+    const float cx = nx * (g.hx - g.shx), dx = nx * (g.hx - g.slx), cy = ny * (g.hy - g.shy), dy = ny * (g.hy - g.sly),
+                cz = nz * (g.hz - g.shz), dz = nz * (g.hz - g.slz);
+    const float dn_lo = fminf(cx, dx) + (fminf(cy, dy) + fminf(cz, dz));
+    const float dn_hi = fmaxf(cx, dx) + (fmaxf(cy, dy) + fmaxf(cz, dz));
+    const float M = g.m0 + 2e-5f * fabsf(nA);
+    const bool sane = (fabsf(nx) + fabsf(ny) + fabsf(nz) <= 4.0f) && (fabsf(nA) <= 1e30f);
+    const bool opposite = (num_lo > M && dn_hi < -M) || (num_hi < -M && dn_lo > M);
+    const float min_abs_num = fmaxf(num_lo, -num_hi);              // <= 0 when the interval straddles zero
+    const float max_abs_dn = fmaxf(fabsf(dn_lo), fabsf(dn_hi));
+    const bool beyond = (min_abs_num - M) >= 0.981f * (max_abs_dn + M);
+    return sane && (num_lo <= num_hi) && (dn_lo <= dn_hi) && (opposite || beyond);
+}
+
 // How a packet walk starts and when it gives work away.
 struct WalkCtl {
     bool resume;                      // leaf task: process chunks [c_begin, c_end) of leaf `start_node` for `start_mask`, nothing else
@@ -218,8 +254,9 @@ struct WalkCtl {
     uint32_t *task_count;
     uint32_t target;                  // estimated cost of one task piece
     uint32_t task_cap;
+    SegPacket seg;                    // shadow units: plane culling (off for every other kind of packet)
 };
-__device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, 0u, 0u, nullptr, nullptr, 1u, 0u}; }
+__device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, 0u, 0u, nullptr, nullptr, 1u, 0u, seg_off()}; }
 
 __device__ __forceinline__ TriRec tri_from_regs(const u32x16 &lo, const u32x4 &hi) {
     TriRec t;
@@ -238,6 +275,16 @@ __device__ __forceinline__ void tri_load_uniform2(const TriRec *p, TriRec &a, Tr
     u32x4 hi0, hi1;
     asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x40\n\ts_load_dwordx16 %2, %4, 0x50\n\ts_load_dwordx4 %3, %4, 0x90\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(lo0), "=&s"(hi0), "=&s"(lo1), "=&s"(hi1) : "s"(p) : "memory");
+    a = tri_from_regs(lo0, hi0);
+    b = tri_from_regs(lo1, hi1);
+}
+
+// same, for two records that are not neighbours
+__device__ __forceinline__ void tri_load_uniform_pair(const TriRec *pa, const TriRec *pb, TriRec &a, TriRec &b) {
+    u32x16 lo0, lo1;
+    u32x4 hi0, hi1;
+    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x40\n\ts_load_dwordx16 %2, %5, 0x0\n\ts_load_dwordx4 %3, %5, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(lo0), "=&s"(hi0), "=&s"(lo1), "=&s"(hi1) : "s"(pa), "s"(pb) : "memory");
     a = tri_from_regs(lo0, hi0);
     b = tri_from_regs(lo1, hi1);
 }
@@ -528,8 +575,12 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
 
 // Flat scenes (the root is itself a small leaf -- cube.obj: 1 node, 12 triangles): no stack, no LDS, no mode choice;
 // every ray that passes the root test steps through the same wave-uniform triangle list (scalar loads).
+// Lane k of the wave keeps the plane (n, n.A) of root triangle k for the whole kernel (k_shadow): one plane_rules_out per
+// unit then tells which of the root's triangles any of the unit's 64 segments can still be blocked by.
+struct LanePlane { float nx, ny, nz, nA; };
+
 template <bool ANY, bool COUNT>
-__device__ __forceinline__ void flat_walk(const rt_node &root, const TriRec *__restrict__ tris, bool in_root,
+__device__ __forceinline__ void flat_walk(const rt_node &root, const TriRec *__restrict__ tris, bool in_root, const SegPacket &seg, const LanePlane &pl,
                                           const float ox, const float oy, const float oz,
                                           const float dx, const float dy, const float dz,
                                           float &best_t, int &best_f, bool &occluded, uint32_t &cnt_box, uint32_t &cnt_ref) {
@@ -558,6 +609,31 @@ __device__ __forceinline__ void flat_walk(const rt_node &root, const TriRec *__r
             best_f = better ? static_cast<int>(tr.face) : best_f;
         }
     };
+    if (ANY && !COUNT && seg.on) {
+        // shadow unit: only the triangles whose plane is crossed between a light sample and the hit point
+        unsigned long long keep = cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull);
+        keep &= ~__ballot(plane_rules_out(seg, pl.nx, pl.ny, pl.nz, pl.nA));
+        RT_PROF_ADD(threadIdx.x & 63, 6, 1); RT_PROF_ADD(threadIdx.x & 63, 1, __popcll(keep));
+        while (keep != 0ull) {
+            const uint32_t k0 = static_cast<uint32_t>(__builtin_ctzll(keep));
+            keep &= keep - 1ull;
+            if (keep != 0ull) {
+                const uint32_t k1 = static_cast<uint32_t>(__builtin_ctzll(keep));
+                keep &= keep - 1ull;
+                TriRec ta, tb;
+                tri_load_uniform_pair(T + k0, T + k1, ta, tb);
+                RT_PROF_ADD(threadIdx.x & 63, 0, 2);
+                test_one(ta);
+                test_one(tb);
+            } else {
+                RT_PROF_ADD(threadIdx.x & 63, 0, 1);
+                test_one(tri_load_uniform(T + k0));
+            }
+            mine = mine && !occluded;
+            if (__ballot(mine) == 0ull) return;
+        }
+        return;
+    }
     uint32_t k = 0;
     for (; k + 1u < cnt; k += 2u) {          // two records per step: two independent chains in flight
         TriRec ta, tb;
@@ -575,12 +651,12 @@ __device__ __forceinline__ void flat_walk(const rt_node &root, const TriRec *__r
 template <bool ANY, bool COUNT, bool FLAT>
 __device__ __forceinline__ void walk(const rt_node &root, const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
                                      const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
-                                     const float extent, const WaveStack stk, const int lane, const WalkCtl wc, bool in_root,
+                                     const float extent, const WaveStack stk, const int lane, const WalkCtl wc, const LanePlane &pl, bool in_root,
                                      const float ox, const float oy, const float oz, const float dx, const float dy, const float dz,
                                      const float bx, const float by, const float bz,
                                      const float brx, const float bry, const float brz,
                                      float &best_t, int &best_f, bool &occluded, uint32_t &cnt_box, uint32_t &cnt_ref) {
-    if (FLAT) flat_walk<ANY, COUNT>(root, tris, in_root, ox, oy, oz, dx, dy, dz, best_t, best_f, occluded, cnt_box, cnt_ref);
+    if (FLAT) flat_walk<ANY, COUNT>(root, tris, in_root, wc.seg, pl, ox, oy, oz, dx, dy, dz, best_t, best_f, occluded, cnt_box, cnt_ref);
     else packet_walk<ANY, COUNT>(nodes, tris, chunks, leaf_chunk0, extent, stk, lane, wc, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz,
                                  brx, bry, brz, best_t, best_f, occluded, cnt_box, cnt_ref);
 }
@@ -680,7 +756,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
         float best_t = 3.402823466e+38f;
         int best_f = -1;
         bool dummy = false;
-        walk<false, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, walk_plain(), in_root, ox, oy, oz, dx, dy, dz, bx, by, bz, brx, bry, brz, best_t, best_f, dummy, c_box, c_ref);
+        walk<false, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, walk_plain(), LanePlane{0.f, 0.f, 0.f, 0.f}, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz, brx, bry, brz, best_t, best_f, dummy, c_box, c_ref);
         const bool hit = valid && (best_f >= 0) && (static_cast<uint32_t>(best_f) < S.n_faces);
         const float hx = ox + best_t * dx, hy = oy + best_t * dy, hz = oz + best_t * dz;   // flyscene.cpp:695
 
@@ -699,7 +775,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
                 const bool sroot = act && box_hit_verified(root.bmin, px, py, pz, sdx, sdy, sdz, srx, sry, srz);
                 float t_unused = 0.f; int f_unused = -1;
                 bool occ = false;
-                walk<true, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, walk_plain(), sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz, srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref);
+                walk<true, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, walk_plain(), LanePlane{0.f, 0.f, 0.f, 0.f}, sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz, srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref);
                 lit = lit || (act && !occ);
             }
         }
@@ -743,12 +819,12 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
     c_rays = wave_sum(c_rays); c_cull = wave_sum(c_cull); c_centre = wave_sum(c_centre);
     if (COUNT) { c_box = wave_sum(c_box); c_ref = wave_sum(c_ref); }
     if (lane == 0) {
-        if (c_rays) atomicAdd((PRIMARY || level == 0) ? &ctl->rays_primary : &ctl->rays_bounce, static_cast<unsigned long long>(c_rays));
-        if (c_cull) atomicAdd(&ctl->pixels_culled, static_cast<unsigned long long>(c_cull));
-        if (c_centre) atomicAdd(&ctl->rays_centre, static_cast<unsigned long long>(c_centre));
+        if (c_rays) atomicAdd((PRIMARY || level == 0) ? &ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_PRIMARY] : &ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_BOUNCE], static_cast<unsigned long long>(c_rays));
+        if (c_cull) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_PIXELS_CULLED], static_cast<unsigned long long>(c_cull));
+        if (c_centre) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_CENTRE], static_cast<unsigned long long>(c_centre));
         if (COUNT) {
-            if (c_box) atomicAdd(&ctl->box_tests, static_cast<unsigned long long>(c_box));
-            if (c_ref) atomicAdd(&ctl->leaf_tri_refs, static_cast<unsigned long long>(c_ref));
+            if (c_box) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_BOX_TESTS], static_cast<unsigned long long>(c_box));
+            if (c_ref) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_LEAF_TRI_REFS], static_cast<unsigned long long>(c_ref));
         }
     }
 }
@@ -947,12 +1023,12 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const rt_node *__restri
     c_rays = wave_sum(c_rays); c_cull = wave_sum(c_cull); c_centre = wave_sum(c_centre);
     if (COUNT) { c_box = wave_sum(c_box); c_ref = wave_sum(c_ref); }
     if (lane == 0) {
-        if (c_rays) atomicAdd((PRIMARY || level == 0) ? &ctl->rays_primary : &ctl->rays_bounce, static_cast<unsigned long long>(c_rays));
-        if (c_cull) atomicAdd(&ctl->pixels_culled, static_cast<unsigned long long>(c_cull));
-        if (c_centre) atomicAdd(&ctl->rays_centre, static_cast<unsigned long long>(c_centre));
+        if (c_rays) atomicAdd((PRIMARY || level == 0) ? &ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_PRIMARY] : &ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_BOUNCE], static_cast<unsigned long long>(c_rays));
+        if (c_cull) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_PIXELS_CULLED], static_cast<unsigned long long>(c_cull));
+        if (c_centre) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_CENTRE], static_cast<unsigned long long>(c_centre));
         if (COUNT) {
-            if (c_box) atomicAdd(&ctl->box_tests, static_cast<unsigned long long>(c_box));
-            if (c_ref) atomicAdd(&ctl->leaf_tri_refs, static_cast<unsigned long long>(c_ref));
+            if (c_box) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_BOX_TESTS], static_cast<unsigned long long>(c_box));
+            if (c_ref) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_LEAF_TRI_REFS], static_cast<unsigned long long>(c_ref));
         }
     }
 }
@@ -989,6 +1065,13 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restr
     const uint32_t slot = N <= 64u ? static_cast<uint32_t>(lane) / N : 0u;
     const uint32_t s_in = N <= 64u ? static_cast<uint32_t>(lane) - slot * N : static_cast<uint32_t>(lane);
     const unsigned long long low = N >= 64u ? ~0ull : ((1ull << N) - 1ull);
+
+    LanePlane plane{0.f, 0.f, 0.f, 0.f};
+    if (FLAT && static_cast<uint32_t>(lane) < (root.count_flags & 0x7fffffffu)) {
+        const TriRec *tp = tris + root.first + lane;
+        plane = LanePlane{tp->nx, tp->ny, tp->nz, tp->nA};
+    }
+    const bool plane_cull = !COUNT && G == 1u && S.plane_cull != 0;
 
     uint32_t c_rays = 0, c_box = 0, c_ref = 0;
     ShardedQueue q;
@@ -1039,6 +1122,19 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restr
         light_sample(L, px, py, pz, static_cast<int>(s), sx, sy, sz);
         const float ddx = hx - sx, ddy = hy - sy, ddz = hz - sz;
         const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
+        if (plane_cull) {
+            // box of this light's sample positions: light_sample is monotone in each sample index, so its first and last
+            // index give the exact extremes
+            float x0, x1, y0, y1, z0, z1;
+            light_sample(L, px, py, pz, 0, x0, y0, z0);
+            light_sample(L, px, py, pz, L.n_samples - 1, x1, y1, z1);
+            wc.seg.on = true;
+            wc.seg.hx = hx; wc.seg.hy = hy; wc.seg.hz = hz;
+            wc.seg.slx = fminf(x0, x1); wc.seg.shx = fmaxf(x0, x1);
+            wc.seg.sly = fminf(y0, y1); wc.seg.shy = fmaxf(y0, y1);
+            wc.seg.slz = fminf(z0, z1); wc.seg.shz = fmaxf(z0, z1);
+            wc.seg.m0 = 2e-5f * ((fabsf(x0) + fabsf(x1)) + (fabsf(y0) + fabsf(y1)) + (fabsf(z0) + fabsf(z1)) + (fabsf(hx) + fabsf(hy) + fabsf(hz)));
+        }
         const unsigned long long vis_index = N <= 64u ? static_cast<unsigned long long>(g) : static_cast<unsigned long long>(g) * P + pass;
         bool sroot;
         if (CONT) {
@@ -1053,7 +1149,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restr
         }
         float t_unused = 0.f; int f_unused = -1;
         bool occ = false;
-        walk<true, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, wc, sroot, sx, sy, sz, ddx, ddy, ddz, ddx, ddy, ddz, srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref);
+        walk<true, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, wc, plane, sroot, sx, sy, sz, ddx, ddy, ddz, ddx, ddy, ddz, srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref);
         if (CONT) {
             const unsigned long long om = __ballot(valid && occ);
             if (N <= 64u) {
@@ -1084,10 +1180,10 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restr
     c_rays = wave_sum(c_rays);
     if (COUNT) { c_box = wave_sum(c_box); c_ref = wave_sum(c_ref); }
     if (lane == 0) {
-        if (c_rays) atomicAdd(&ctl->rays_sample, static_cast<unsigned long long>(c_rays));
+        if (c_rays) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_SAMPLE], static_cast<unsigned long long>(c_rays));
         if (COUNT) {
-            if (c_box) atomicAdd(&ctl->box_tests_shadow, static_cast<unsigned long long>(c_box));
-            if (c_ref) atomicAdd(&ctl->leaf_tri_refs_shadow, static_cast<unsigned long long>(c_ref));
+            if (c_box) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_BOX_TESTS_SHADOW], static_cast<unsigned long long>(c_box));
+            if (c_ref) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_LEAF_TRI_REFS_SHADOW], static_cast<unsigned long long>(c_ref));
         }
     }
 }
@@ -1264,7 +1360,7 @@ __global__ __launch_bounds__(256) void k_shade(const DScene S, const DLights L, 
     }
     c_shaded = wave_sum(c_shaded);
     (void)c_spawn;
-    if (lane == 0 && c_shaded) atomicAdd(&ctl->shaded_hits, static_cast<unsigned long long>(c_shaded));
+    if (lane == 0 && c_shaded) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_SHADED_HITS], static_cast<unsigned long long>(c_shaded));
 }
 
 // ======================================================================================================

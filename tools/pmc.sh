@@ -15,5 +15,12 @@ for part in ("a","b"):
             k = row["Kernel_Name"].split("(")[0][:40]
             agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         for k, d in agg.items():
-            if "rtamd" in k: print(part, k, {c: round(v) for c, v in d.items()})
+            if "rtamd" in k:
+                print(part, k, {c: round(v) for c, v in d.items()})
+                if "GRBM_GUI_ACTIVE" in d and d["GRBM_GUI_ACTIVE"] > 0:
+                    cyc = d["GRBM_GUI_ACTIVE"] / 8.0           # rocprofv3 sums the 8 XCDs
+                    # one wave64 VALU instruction occupies its SIMD for one quad-cycle; 256 CUs x 4 SIMDs
+                    print("   VALU utilisation %.3f  SALU/VALU %.2f  mean resident waves/SIMD %.2f" % (
+                        d["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cyc), d["SQ_INSTS_SALU"] / max(d["SQ_INSTS_VALU"], 1.0),
+                        d["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * cyc)))
 PY
