@@ -19,8 +19,8 @@ namespace rtamd {
 void launch_trace(bool primary, bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DCam *camp, const DLights &L, const DFrame &F,
                   int level, int slot, const RayItem *rays_in, ShadeItem *items, Control *ctl, float4 *rec, int32_t *out_hit, float *out_t);
 void launch_shadow(bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
-                   const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target);
-void launch_shadow_cont(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, const ShadeItem *items,
+                   uint32_t item_cap, const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target);
+void launch_shadow_cont(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, uint32_t item_cap, const ShadeItem *items,
                         Control *ctl, unsigned long long *vis, const ContTask *tasks_in, ContTask *tasks_out, uint32_t q_in, uint32_t q_out,
                         uint32_t cap, uint32_t budget);
 void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level, int slot, int lslots,
@@ -462,8 +462,18 @@ static rt_status check_lights(rt_ctx *c, const rt_lights *l, DLights *out) {
     return RT_OK;
 }
 
-static rt_status ensure_frame(rt_ctx *c, size_t npix, int levels, size_t vis_words, size_t tiles, size_t lslots) {
+// Sizes of the per-frame lists.  `tiles` bounds the dense tile/group numbering of every level: the primary 8x8 tiles, or
+// ceil(n/64) + RT_LIST_SHARDS for a sharded list of n <= npix elements (each shard rounds up to whole groups of 64).  A
+// list shard receives the elements of every RT_LIST_SHARDS-th tile, hence the per-shard capacity.
+static size_t frame_tiles(const DFrame &F) {
+    return std::max(static_cast<size_t>(F.tiles_x) * static_cast<size_t>(F.tiles_y), static_cast<size_t>(F.npix) / 64 + 1 + RT_LIST_SHARDS);
+}
+static uint32_t list_cap(size_t tiles) { return static_cast<uint32_t>(((tiles + RT_LIST_SHARDS - 1) / RT_LIST_SHARDS + 1) * 64); }
+
+static rt_status ensure_frame(rt_ctx *c, size_t npix_frame, int levels, size_t samples_words, size_t tiles, size_t lslots) {
     const size_t lit_words = tiles * lslots, best_slots = tiles * 64;
+    const size_t npix = std::max(npix_frame, static_cast<size_t>(list_cap(tiles)) * RT_LIST_SHARDS);   // list storage (all shards)
+    const size_t vis_words = npix * lslots * samples_words;
     if (npix > c->cap_pix || levels > c->cap_levels || vis_words > c->cap_vis || lit_words > c->cap_lit || best_slots > c->cap_best) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         const size_t np = npix > c->cap_pix ? npix : c->cap_pix;
@@ -506,12 +516,13 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
     const int levels_run = c->reflective ? D + 1 : 1;
     const int lslots = L.n_lights;
     const size_t P = (static_cast<size_t>(L.n_samples) + 63) / 64;
-    const size_t tiles = std::max(static_cast<size_t>(F.tiles_x) * static_cast<size_t>(F.tiles_y), static_cast<size_t>(F.npix) / 64 + 1);
-    rt_status s = ensure_frame(c, F.npix, D + 1, static_cast<size_t>(F.npix) * lslots * P, tiles, static_cast<size_t>(lslots));
+    const size_t tiles = frame_tiles(F);
+    rt_status s = ensure_frame(c, F.npix, D + 1, P, tiles, static_cast<size_t>(lslots));
     if (s != RT_OK) return s;
+    F.item_cap = F.ray_cap = list_cap(tiles);
     HIPCHK(c, hipMemsetAsync(c->d_ctl, 0, sizeof(Control), st));
     launch_set_prof(st, c->d_ctl);   // no-op unless built with -DRT_PROFILE
-    if (!primary) HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->d_ctl->n_rays[0]), static_cast<int>(n_input_rays), 1, st));
+    if (!primary) HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->d_ctl->n_rays[0][0]), static_cast<int>(n_input_rays), 1, st));
     size_t ev = c->ev_base;
     if (cam) {   // asynchronous camera upload through the pinned ring (skipped when replaying a captured graph)
         DCam *slot = &c->h_cam_ring[c->cam_slot++ % kCamRing];
@@ -546,10 +557,10 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
                          c->d_best, c->d_lit, TaskQueues{nullptr, nullptr, 0u, 0u, cap, 0u});
         }
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
-        launch_shadow(count, c->flat, c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, c->d_items, c->d_ctl, c->d_vis,
+        launch_shadow(count, c->flat, c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis,
                       c->d_tasks[0], c->task_cap, c->shadow_budget, c->task_target);
         if (!c->flat && !count && c->shadow_budget != 0u)      // the big leaves of the shadow units, spread over all waves
-            launch_shadow_cont(c->cus * c->occ_shadow, st, c->S, L, level, lslots, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[0], nullptr, 2u, 0u,
+            launch_shadow_cont(c->cus * c->occ_shadow, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[0], nullptr, 2u, 0u,
                                c->task_cap, 0u);
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));   // after the whole shadow group (incl. continuations)
         launch_shade(c->cus * c->occ_shade, st, c->S, L, F, level, 3 * level + 2, lslots, c->d_items, c->d_ctl, c->d_vis, rec_l, fres_l, c->d_rays[(level + 1) & 1]);
@@ -590,7 +601,7 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
     Control h;
     HIPCHK(c, hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
     fold_stats(h);
-    if (std::getenv("RT_DEBUG")) std::fprintf(stderr, "RT_DEBUG level0: items %u tasks closest %u %u centre %u %u shadow %u %u\n", h.n_items[0], h.n_tasks[0][0], 0u, h.n_tasks[0][1], 0u, h.n_tasks[0][2], 0u);
+    if (std::getenv("RT_DEBUG")) std::fprintf(stderr, "RT_DEBUG level0: items %u tasks closest %u %u centre %u %u shadow %u %u\n", [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_items[0][sh * 16]; return t; }(), h.n_tasks[0][0], 0u, h.n_tasks[0][1], 0u, h.n_tasks[0][2], 0u);
     out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample;
     out->pixels = F.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;
 #ifdef RT_PROFILE
@@ -712,8 +723,7 @@ extern "C" rt_status rt_graph_create(rt_ctx *c, const rt_lights *lights, const r
     if (F.npix == 0) { c->err = "rt_graph_create: empty shard"; return RT_ERR_INVALID; }
     // every allocation happens BEFORE the capture
     const size_t P = (static_cast<size_t>(L.n_samples) + 63) / 64;
-    if ((s = ensure_frame(c, F.npix, F.max_depth + 1, static_cast<size_t>(F.npix) * L.n_lights * P,
-                          std::max(static_cast<size_t>(F.tiles_x) * static_cast<size_t>(F.tiles_y), static_cast<size_t>(F.npix) / 64 + 1), static_cast<size_t>(L.n_lights))) != RT_OK) return s;
+    if ((s = ensure_frame(c, F.npix, F.max_depth + 1, P, frame_tiles(F), static_cast<size_t>(L.n_lights))) != RT_OK) return s;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     rt_graph *g = new rt_graph();
     g->ctx = c; g->F = F; g->generation = c->frame_generation;
@@ -833,8 +843,7 @@ extern "C" rt_status rt_trace_rays(rt_ctx *c, const rt_lights *lights, int32_t m
     F.max_depth = max_depth < 0 ? RT_MAX_DEPTH : max_depth;
     F.dyn_trace = c->dyn_trace;
     const size_t P = (static_cast<size_t>(L.n_samples) + 63) / 64;
-    if ((s = ensure_frame(c, F.npix, F.max_depth + 1, static_cast<size_t>(F.npix) * L.n_lights * P,
-                          std::max(static_cast<size_t>(F.tiles_x) * static_cast<size_t>(F.tiles_y), static_cast<size_t>(F.npix) / 64 + 1), static_cast<size_t>(L.n_lights))) != RT_OK) return s;
+    if ((s = ensure_frame(c, F.npix, F.max_depth + 1, P, frame_tiles(F), static_cast<size_t>(L.n_lights))) != RT_OK) return s;
     std::vector<RayItem> rays(static_cast<size_t>(n));
     for (int32_t i = 0; i < n; ++i) {
         RayItem &r = rays[static_cast<size_t>(i)];

@@ -666,6 +666,47 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+// ---- sharded compaction lists (rt_device.hpp, RT_LIST_SHARDS) ----
+// Lane s (< RT_LIST_SHARDS) of a ShardMap holds shard s: its element count and where its work units start in the dense
+// numbering [0, total) of the consumer's work (tiles of 64 elements, or shadow units).
+struct ShardMap {
+    uint32_t start, next, cnt;   // per lane
+    uint32_t total;              // uniform
+};
+__device__ __forceinline__ ShardMap shard_map(const uint32_t *counters, const int lane, const uint32_t cap, const uint32_t mult, const uint32_t gran) {
+    uint32_t c = lane < RT_LIST_SHARDS ? counters[lane * 16] : 0u;
+    if (c > cap) c = cap;
+    const uint32_t w = static_cast<uint32_t>((static_cast<unsigned long long>(c) * mult + gran - 1u) / gran);
+    uint32_t incl = w;
+    for (int d = 1; d < RT_LIST_SHARDS; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    ShardMap m;
+    m.cnt = c;
+    m.start = incl - w;
+    m.next = lane < RT_LIST_SHARDS ? incl : 0xffffffffu;
+    m.total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), RT_LIST_SHARDS - 1));
+    return m;
+}
+// dense work number w (wave-uniform, < total) -> shard, work number inside the shard, the shard's element count
+__device__ __forceinline__ void shard_find(const ShardMap &m, const uint32_t w, uint32_t &shard, uint32_t &local, uint32_t &cnt) {
+    shard = static_cast<uint32_t>(__popcll(__ballot(m.next <= w)));
+    if (shard >= RT_LIST_SHARDS) shard = RT_LIST_SHARDS - 1;     // never taken for w < total
+    local = w - static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(m.start), static_cast<int>(shard)));
+    cnt = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(m.cnt), static_cast<int>(shard)));
+}
+// one returning atomic per wave on the counter of the list shard picked by the producing tile / group number
+__device__ __forceinline__ uint32_t shard_reserve(uint32_t *counters, const uint32_t producer, const uint32_t n, const uint32_t cap, const int lane,
+                                                  bool &fits) {
+    const uint32_t sh = producer & (RT_LIST_SHARDS - 1u);
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&counters[sh * 16u], n);
+    base = uniform_u32(base);
+    fits = base + n <= cap;       // always true: the capacity is derived from the tile count (rt_capi.cpp, list_caps)
+    return sh * cap + base;
+}
+
 // arealight::getPointLights / createSpherePoint (arealight.hpp:15-25, flyscene.cpp:956-972): sample s of light p
 __device__ __forceinline__ void light_sample(const DLights &L, const float px, const float py, const float pz, const int s,
                                              float &sx, float &sy, float &sz) {
@@ -696,8 +737,9 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
     __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, s_stage + wave * RT_STAGE_TRIS * 5};
-    const uint32_t n_in = PRIMARY ? 0u : ctl->n_rays[level];
-    const uint32_t ntiles = PRIMARY ? static_cast<uint32_t>(F.tiles_x) * static_cast<uint32_t>(F.tiles_y) : (n_in + 63u) / 64u;
+    ShardMap rmap{0u, 0u, 0u, 0u};
+    if (!PRIMARY) rmap = shard_map(ctl->n_rays[level], lane, 0xffffffffu, 1u, 64u);
+    const uint32_t ntiles = PRIMARY ? static_cast<uint32_t>(F.tiles_x) * static_cast<uint32_t>(F.tiles_y) : rmap.total;
     const rt_node root = nodes[0];
     // the camera lives in device memory so that a captured hipGraph of the frame can be replayed with a new camera
     DCam cam;
@@ -739,9 +781,11 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
             c_cull += (valid && !pre) ? 1u : 0u;
             in_root = pre;
         } else {
-            const uint32_t r = tile * 64u + static_cast<uint32_t>(lane);
+            uint32_t sh, tj, n_in;
+            shard_find(rmap, tile, sh, tj, n_in);
+            const uint32_t r = tj * 64u + static_cast<uint32_t>(lane);
             valid = r < n_in;
-            const RayItem it = rays_in[valid ? r : 0u];
+            const RayItem it = rays_in[valid ? sh * F.ray_cap + r : 0u];
             ox = it.ox; oy = it.oy; oz = it.oz; dx = it.dx; dy = it.dy; dz = it.dz;
             lx = it.lx; ly = it.ly; lz = it.lz; lmode = it.lmode; pix = it.pix;
             in_root = valid;
@@ -789,10 +833,9 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
         // compaction: lit hits -> shade list (wave ballot + prefix, one atomic per wave)
         const unsigned long long lm = __ballot(lit);
         if (lm != 0ull) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&ctl->n_items[level], static_cast<uint32_t>(__popcll(lm)));
-            base = uniform_u32(base);
-            if (lit) {
+            bool fits;
+            const uint32_t base = shard_reserve(ctl->n_items[level], tile, static_cast<uint32_t>(__popcll(lm)), F.item_cap, lane, fits);
+            if (lit && fits) {
                 ShadeItem o;
                 o.ox = ox; o.oy = oy; o.oz = oz; o.dx = dx; o.dy = dy; o.dz = dz;
                 o.lx = lx; o.ly = ly; o.lz = lz; o.lmode = lmode; o.pix = pix; o.face = best_f; o.t = best_t;
@@ -848,7 +891,7 @@ struct TileRay {
 
 template <bool PRIMARY>
 __device__ __forceinline__ TileRay tile_ray(const uint32_t tile, const int lane, const DFrame &F, const DCam &cam, const rt_node &root,
-                                            const RayItem *__restrict__ rays_in, const uint32_t n_in) {
+                                            const RayItem *__restrict__ rays_in, const ShardMap &rmap) {
     TileRay r;
     r.lx = r.ly = r.lz = 0.f; r.lmode = 0u;
     if (PRIMARY) {
@@ -873,9 +916,11 @@ __device__ __forceinline__ TileRay tile_ray(const uint32_t tile, const int lane,
         r.pre = r.valid && box_hit_verified(root.bmin, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, __builtin_amdgcn_rcpf(r.dx),
                                             __builtin_amdgcn_rcpf(r.dy), __builtin_amdgcn_rcpf(r.dz));                 // flyscene.cpp:576
     } else {
-        const uint32_t k = tile * 64u + static_cast<uint32_t>(lane);
+        uint32_t sh, tj, n_in;
+        shard_find(rmap, tile, sh, tj, n_in);
+        const uint32_t k = tj * 64u + static_cast<uint32_t>(lane);
         r.valid = k < n_in;
-        const RayItem it = rays_in[r.valid ? k : 0u];
+        const RayItem it = rays_in[r.valid ? sh * F.ray_cap + k : 0u];
         r.ox = it.ox; r.oy = it.oy; r.oz = it.oz; r.dx = it.dx; r.dy = it.dy; r.dz = it.dz;
         r.lx = it.lx; r.ly = it.ly; r.lz = it.lz; r.lmode = it.lmode; r.pix = it.pix;
         r.pre = r.valid;
@@ -899,8 +944,9 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const rt_node *__restri
     __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, s_stage + wave * RT_STAGE_TRIS * 5};
-    const uint32_t n_in = PRIMARY ? 0u : ctl->n_rays[level];
-    const uint32_t ntiles = PRIMARY ? static_cast<uint32_t>(F.tiles_x) * static_cast<uint32_t>(F.tiles_y) : (n_in + 63u) / 64u;
+    ShardMap rmap{0u, 0u, 0u, 0u};
+    if (!PRIMARY) rmap = shard_map(ctl->n_rays[level], lane, 0xffffffffu, 1u, 64u);
+    const uint32_t ntiles = PRIMARY ? static_cast<uint32_t>(F.tiles_x) * static_cast<uint32_t>(F.tiles_y) : rmap.total;
     const rt_node root = nodes[0];
     DCam cam;
     if (PRIMARY) cam = *camp;
@@ -931,7 +977,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const rt_node *__restri
         }
         const uint32_t tile = STAGE == 1 ? unit / static_cast<uint32_t>(lslots) : unit;
         const int l = STAGE == 1 ? static_cast<int>(unit - tile * static_cast<uint32_t>(lslots)) : 0;
-        const TileRay r = tile_ray<PRIMARY>(tile, lane, F, cam, root, rays_in, n_in);
+        const TileRay r = tile_ray<PRIMARY>(tile, lane, F, cam, root, rays_in, rmap);
         const size_t ray_slot = static_cast<size_t>(tile) * 64u + static_cast<size_t>(lane);
 
         if (STAGE == 0) {
@@ -1006,10 +1052,9 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const rt_node *__restri
                 }
                 const unsigned long long lm = __ballot(is_lit);
                 if (lm != 0ull) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&ctl->n_items[level], static_cast<uint32_t>(__popcll(lm)));
-                    base = uniform_u32(base);
-                    if (is_lit) {
+                    bool fits;
+                    const uint32_t base = shard_reserve(ctl->n_items[level], tile, static_cast<uint32_t>(__popcll(lm)), F.item_cap, lane, fits);
+                    if (is_lit && fits) {
                         ShadeItem o;
                         o.ox = r.ox; o.oy = r.oy; o.oz = r.oz; o.dx = r.dx; o.dy = r.dy; o.dz = r.dz;
                         o.lx = r.lx; o.ly = r.ly; o.lz = r.lz; o.lmode = r.lmode; o.pix = r.pix; o.face = best_f; o.t = best_t;
@@ -1047,20 +1092,20 @@ template <bool COUNT, bool FLAT, bool CONT>
 __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
                                                           const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                                            const DScene S, const DLights L, const int level, const int ctr_slot,
-                                                           const int lslots, const ShadeItem *__restrict__ items,
+                                                           const int lslots, const uint32_t item_cap, const ShadeItem *__restrict__ items,
                                                            Control *__restrict__ ctl, unsigned long long *vis, const TaskQueues Q) {
     __shared__ uint4 s_stage[RT_WAVES * RT_STAGE_TRIS * 5];
     __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
     __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, s_stage + wave * RT_STAGE_TRIS * 5};
-    const uint32_t n_items = ctl->n_items[level];
     const uint32_t N = static_cast<uint32_t>(L.n_samples);
-    const uint32_t groups = n_items * static_cast<uint32_t>(lslots);
     const uint32_t G = N <= 64u ? 64u / N : 1u;              // (hit,light) pairs per wave
     const uint32_t P = (N + 63u) / 64u;                       // 64-sample passes (= mask words) per pair
-    const unsigned long long units = N <= 64u ? (static_cast<unsigned long long>(groups) + G - 1u) / G
-                                              : static_cast<unsigned long long>(groups) * P;
+    // units of list shard s: ceil(cnt_s * lslots / G) (N <= 64) or cnt_s * lslots * P (N > 64), numbered shard after shard
+    const ShardMap imap = N <= 64u ? shard_map(ctl->n_items[level], lane, item_cap, static_cast<uint32_t>(lslots), G)
+                                   : shard_map(ctl->n_items[level], lane, item_cap, static_cast<uint32_t>(lslots) * P, 1u);
+    const unsigned long long units = imap.total;
     const rt_node root = nodes[0];
     const uint32_t slot = N <= 64u ? static_cast<uint32_t>(lane) / N : 0u;
     const uint32_t s_in = N <= 64u ? static_cast<uint32_t>(lane) - slot * N : static_cast<uint32_t>(lane);
@@ -1103,17 +1148,22 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restr
             wc.target = Q.target ? Q.target : Q.budget;
         }
         uint32_t g, s, pass = 0;
-        bool valid;
+        bool valid, slot_ok = false;
+        uint32_t sh, lu, n_sh;
+        shard_find(imap, unit, sh, lu, n_sh);
+        const uint32_t groups = n_sh * static_cast<uint32_t>(lslots);     // (hit, light) pairs of this list shard
         if (N <= 64u) {
-            g = unit * G + slot; s = s_in;
+            g = lu * G + slot; s = s_in;
             valid = (slot < G) && (g < groups);
+            slot_ok = valid;
         } else {
-            g = unit / P; pass = unit - g * P; s = pass * 64u + s_in;
+            g = lu / P; pass = lu - g * P; s = pass * 64u + s_in;
             valid = s < N;
         }
         const uint32_t item_i = valid ? g / static_cast<uint32_t>(lslots) : 0u;
         const int l = valid ? static_cast<int>(g - item_i * static_cast<uint32_t>(lslots)) : 0;
-        const ShadeItem it = items[item_i];
+        const ShadeItem it = items[sh * item_cap + item_i];
+        g += sh * item_cap * static_cast<uint32_t>(lslots);               // (item storage index) * lslots + light: the vis slot
         const int nl = it.lmode ? 1 : L.n_lights;
         valid = valid && (l < nl);
         const float hx = it.ox + it.t * it.dx, hy = it.oy + it.t * it.dy, hz = it.oz + it.t * it.dz;
@@ -1154,14 +1204,14 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restr
             const unsigned long long om = __ballot(valid && occ);
             if (N <= 64u) {
                 const unsigned long long word = (om >> (slot * N)) & low;
-                if (s_in == 0u && slot < G && g < groups && word != 0ull) atomicAnd(&vis[vis_index], ~word);
+                if (s_in == 0u && slot_ok && word != 0ull) atomicAnd(&vis[vis_index], ~word);
             } else if (lane == 0 && om != 0ull) {
                 atomicAnd(&vis[vis_index], ~om);
             }
         } else {
             const unsigned long long vm = __ballot(valid && !occ);
             if (N <= 64u) {
-                if (s_in == 0u && slot < G && g < groups) vis[vis_index] = (vm >> (slot * N)) & low;
+                if (s_in == 0u && slot_ok) vis[vis_index] = (vm >> (slot * N)) & low;
             } else if (lane == 0) {
                 vis[vis_index] = vm;
             }
@@ -1229,17 +1279,19 @@ __global__ __launch_bounds__(256) void k_shade(const DScene S, const DLights L, 
                                                const unsigned long long *__restrict__ vis, float4 *__restrict__ rec,
                                                float *__restrict__ fres, RayItem *__restrict__ rays_out) {
     const int lane = threadIdx.x & 63;
-    const uint32_t n_items = ctl->n_items[level];
-    const uint32_t ntiles = (n_items + 63u) / 64u;
+    const ShardMap imap = shard_map(ctl->n_items[level], lane, F.item_cap, 1u, 64u);      // groups of 64 items, shard after shard
+    const uint32_t ntiles = imap.total;
     const uint32_t N = static_cast<uint32_t>(L.n_samples);
     const uint32_t P = (N + 63u) / 64u;
     uint32_t c_shaded = 0, c_spawn = 0;
     const uint32_t wave_id = uniform_u32(blockIdx.x * 4u + (threadIdx.x >> 6));
     const uint32_t wave_count = gridDim.x * 4u;
     for (uint32_t tile = wave_id; tile < ntiles; tile += wave_count) {
-        const uint32_t idx = tile * 64u + static_cast<uint32_t>(lane);
-        const bool valid = idx < n_items;
-        const ShadeItem it = items[valid ? idx : 0u];
+        uint32_t sh, tj, n_sh;
+        shard_find(imap, tile, sh, tj, n_sh);
+        const bool valid = tj * 64u + static_cast<uint32_t>(lane) < n_sh;
+        const uint32_t idx = sh * F.item_cap + tj * 64u + static_cast<uint32_t>(lane);     // item storage index (also keys vis)
+        const ShadeItem it = items[valid ? idx : sh * F.item_cap];
         bool spawn = false;
         RayItem child;
         child.pad = 0u;
@@ -1352,10 +1404,9 @@ __global__ __launch_bounds__(256) void k_shade(const DScene S, const DLights L, 
         }
         const unsigned long long sm = __ballot(spawn);
         if (sm != 0ull) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&ctl->n_rays[level + 1], static_cast<uint32_t>(__popcll(sm)));
-            base = uniform_u32(base);
-            if (spawn) { rays_out[base + lanes_below(sm)] = child; c_spawn += 1; }
+            bool fits;
+            const uint32_t base = shard_reserve(ctl->n_rays[level + 1], tile, static_cast<uint32_t>(__popcll(sm)), F.ray_cap, lane, fits);
+            if (spawn && fits) { rays_out[base + lanes_below(sm)] = child; c_spawn += 1; }
         }
     }
     c_shaded = wave_sum(c_shaded);
@@ -1502,9 +1553,9 @@ void launch_stage(bool primary, bool count, int stage, bool cont, int grid, hipS
     }
 }
 
-#define RT_LAUNCH_SHADOW(C, F, K) hipLaunchKernelGGL((k_shadow<C, F, K>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, L, level, slot, lslots, items, ctl, vis, Q)
+#define RT_LAUNCH_SHADOW(C, F, K) hipLaunchKernelGGL((k_shadow<C, F, K>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, L, level, slot, lslots, item_cap, items, ctl, vis, Q)
 void launch_shadow(bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
-                   const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target) {
+                   uint32_t item_cap, const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target) {
     const dim3 g(grid), b(RT_WAVES * 64);
     const TaskQueues Q{nullptr, (flat || count) ? nullptr : tasks_out, 0u, 2u, cap, (flat || count) ? 0u : budget, target};
     if (count) { if (flat) RT_LAUNCH_SHADOW(true, true, false); else RT_LAUNCH_SHADOW(true, false, false); }
@@ -1512,7 +1563,7 @@ void launch_shadow(bool count, bool flat, int grid, hipStream_t st, const DScene
 }
 
 // processes the leaf tasks of queue q_in (leaf tasks never create new tasks)
-void launch_shadow_cont(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, const ShadeItem *items,
+void launch_shadow_cont(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, uint32_t item_cap, const ShadeItem *items,
                         Control *ctl, unsigned long long *vis, const ContTask *tasks_in, ContTask *tasks_out, uint32_t q_in, uint32_t q_out,
                         uint32_t cap, uint32_t budget) {
     const dim3 g(grid), b(RT_WAVES * 64);
