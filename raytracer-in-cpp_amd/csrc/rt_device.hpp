@@ -150,7 +150,9 @@ struct DFrame {              // which pixels this launch covers
 // unit at ~88 per us (9,000 tiles of cube.obj at 1080p = 0.1 ms, measured as the floor of k_trace and of k_shade).
 // Element i of shard s lives at index s * cap + i; the producing tile/group number picks the shard (tile % RT_LIST_SHARDS),
 // so the per-shard capacity is known up front.
+#ifndef RT_LIST_SHARDS
 #define RT_LIST_SHARDS 16
+#endif
 enum : int { ST_RAYS_PRIMARY = 0, ST_RAYS_BOUNCE, ST_RAYS_CENTRE, ST_RAYS_SAMPLE, ST_PIXELS_CULLED, ST_SHADED_HITS,
              ST_BOX_TESTS, ST_LEAF_TRI_REFS, ST_BOX_TESTS_SHADOW, ST_LEAF_TRI_REFS_SHADOW };
 

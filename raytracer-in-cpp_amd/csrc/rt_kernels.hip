@@ -1088,8 +1088,12 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const rt_node *__restri
 // occluded bits into `vis` with atomicAnd.  (A first version handed over whole sub-trees once a unit was over budget: the
 // pieces were still 979-triangle leaves and the passes ran back to back -- no gain.)
 
+// 97 VGPRs would cost the tree variants their fifth wave per SIMD; asked for 5, the allocator finds them without spilling
+#ifndef RT_SHADOW_WPE
+#define RT_SHADOW_WPE 5
+#endif
 template <bool COUNT, bool FLAT, bool CONT>
-__global__ __launch_bounds__(RT_WAVES * 64) void k_shadow(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
+__global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(RT_SHADOW_WPE, 8))) void k_shadow(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
                                                           const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                                            const DScene S, const DLights L, const int level, const int ctr_slot,
                                                            const int lslots, const uint32_t item_cap, const ShadeItem *__restrict__ items,
@@ -1274,7 +1278,12 @@ __device__ __forceinline__ float fresnel_term(float ix, float iy, float iz, floa
     return (Rs * Rs + Rp * Rp) / 2;
 }
 
-__global__ __launch_bounds__(256) void k_shade(const DScene S, const DLights L, const DFrame F, const int level, const int ctr_slot,
+// 4 waves per SIMD (128 VGPRs, 88 B of scratch) instead of 3 (149 VGPRs): -7 % on the 576k-item cube frame
+#ifndef RT_SHADE_WPE
+#define RT_SHADE_WPE 4
+#endif
+#define RT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(RT_SHADE_WPE, 8)))
+__global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, const DLights L, const DFrame F, const int level, const int ctr_slot,
                                                const int lslots, const ShadeItem *__restrict__ items, Control *__restrict__ ctl,
                                                const unsigned long long *__restrict__ vis, float4 *__restrict__ rec,
                                                float *__restrict__ fres, RayItem *__restrict__ rays_out) {
