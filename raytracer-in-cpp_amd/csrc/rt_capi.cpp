@@ -608,6 +608,7 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
     if (!counted) {
         std::fprintf(stderr, "RT_PROFILE ray-mode steps %llu useful %llu | tri-mode steps %llu useful %llu | box steps %llu useful %llu | leaves ray %llu tri %llu live-at-tri %llu | cone-culled pairs %llu guard-culled %llu guard-kept %llu\n",
                      h.prof[0], h.prof[1], h.prof[2], h.prof[3], h.prof[4], h.prof[5], h.prof[6], h.prof[7], h.prof[8], h.prof[14], h.prof[12], h.prof[13]);
+        std::fprintf(stderr, "RT_PROFILE plane cull: ray-mode triangles skipped %llu, tri-mode chunks skipped %llu\n", h.prof[64], h.prof[65]);
         std::fprintf(stderr, "RT_PROFILE shadow units %llu: cycles max %llu mean %.0f; log2 histogram:", h.prof[11], h.prof[9], h.prof[11] ? double(h.prof[10]) / double(h.prof[11]) : 0.0);
         for (int b = 8; b <= 30; ++b) std::fprintf(stderr, " [2^%d]=%llu", b, h.prof[16 + b]);
         std::fprintf(stderr, "\n");

@@ -172,7 +172,7 @@ struct Control {
     // whose arithmetic needs < 20 us.)
     unsigned long long stat[RT_STAT_SHARDS][16];
     // -DRT_PROFILE builds only: executed work (wave steps) and useful lane work per leaf mode / box tests
-    unsigned long long prof[64];
+    unsigned long long prof[96];
 };
 
 inline void fold_stats(Control &h) {
