@@ -197,14 +197,22 @@ static rt_status upload(rt_ctx *c, void **dst, const T *src, size_t n) {
 // reference evaluates it in float (flyscene.cpp:787-819).  That evaluation accepts a triangle when the barycentric
 // coordinates of the COMPUTED point P = o + t*d (projected on the triangle's plane) pass u>=0, v>=0, u+v<1.
 //   (1) P lies on the ray line up to rounding (~1e-7 * |P|), whatever the error of t.
-//   (2) When |d.n| >= tau*|d||n| (tau = 0.002), the relative error of d.n is <= 3*eps/tau ~ 9e-5 and the cancellation
-//       error of (n.A - o.n) is <= ~6e-8*(|A|+|o|), so P is within ~9e-5*(|o|+extent) of the triangle's plane.
-//   (3) With kappa = d00*d11/denom (conditioning of the reference's barycentric solve) and P within a few edge lengths,
-//       the errors of u and v are <= ~20*eps*kappa, i.e. P's projection is inside the triangle grown by 1.2e-6*kappa*edge.
-//   => an accepted hit implies the ray LINE passes within  9e-5*(|o|+extent) + 1.2e-6*kappa*edge  of the triangle.
-// So the chunk AABB is inflated by max(5e-6*kappa*edge) + 1e-3*max_edge + 1e-4*extent here (kappa <= 1e4 required), the kernel adds 4e-4*(|o|_1+extent) per ray (4x safety), and
-// the skip additionally requires |d.n| > tau*|d| for EVERY triangle of the chunk (evaluated per triangle in the kernel,
-// lanes = triangles: near-parallel rays make t, and hence P, arbitrarily wrong -- those pairs are always tested).
+//   (2) P is close to the triangle's plane whatever the angle between ray and plane.  With the computed num = n.A - o.n
+//       (absolute error dn_ <= ~3e-7*(|A|+|o|)), den = d.n (absolute error dd_ <= ~3e-7*|d|) and t = num/den*(1+e), |e| <= 1e-7:
+//           n.P - n.A = t*(den - dd_) - (num - dn_) = num*e - t*dd_ + dn_
+//       so |dist(P, plane)| <= 1e-7*|num| + |t|*3e-7*|d| + 3e-7*(|A|+|o|) -- no division by den anywhere.  If |t||d| <= 4(|o|+extent)
+//       this is <= ~2e-6*(|o|+extent).  If |t||d| > 4(|o|+extent), P is more than 2.3*extent away from the origin along some
+//       axis, i.e. far outside every triangle, and so is its projection (P is within 3e-7*|t||d| of the plane): the true
+//       barycentrics are >= ~1.3 in magnitude and their relative error (3) cannot flip a sign -- never accepted.
+//   (3) With kappa = d00*d11/denom (conditioning of the reference's barycentric solve) the errors of u and v are
+//       <= ~20*eps*kappa*(1+|u|+|v|), i.e. P's projection is inside the triangle grown by 1.2e-6*kappa*edge.
+//   => an accepted hit implies the computed point P = o + t*d lies within  2e-6*(|o|+extent) + 1.2e-6*kappa*edge  of the
+//      triangle, hence inside the chunk's inflated box, and t itself lies in the box's [t_in, t_out] of that line.
+// So the chunk AABB is inflated by max(5e-6*kappa*edge) + 1e-3*max_edge + 1e-4*extent here (kappa <= 1e4 required) and the
+// kernel adds 4e-4*(|o|_1+extent) per ray; a ray skips a chunk when its line misses that box or [t_in, t_out] lies outside
+// the t range a hit can count in.  (An earlier version also demanded |d.n| > 0.002|d| for every triangle of the chunk, from
+// a bound on dist(P, plane) that went through the RELATIVE error of d.n; the absolute form above makes that guard, and the
+// per-chunk normal cone that short-cut it, unnecessary: -7 % instructions on dodgeColorTest.obj's k_shadow.)
 // Chunks holding an ill-conditioned, degenerate, non-unit-normal or non-finite triangle are never cullable.
 // ---------------------------------------------------------------------------------------------------------------
 static uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {

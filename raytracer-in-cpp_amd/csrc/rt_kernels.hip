@@ -389,9 +389,6 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                 const ChunkBound *__restrict__ cbounds = chunks + leaf_chunk0[ni];
                 // per-ray quantities of the conservative chunk test (approximate arithmetic is fine: they only ever SKIP
                 // work); computed per leaf visit so that scenes that never take this mode (the cube) pay nothing
-                const float q_len = dx * dx + dy * dy + dz * dz;
-                const float d_len = sqrtf(q_len);
-                const float guard_len = 0.002f * 1.001f * d_len;                  // tau * |d|, tau = 0.002
                 const float idx_ = fabsf(dx) > 1e-30f ? 1.0f / dx : copysignf(1e30f, dx);   // never inf: no inf*0 NaNs
                 const float idy_ = fabsf(dy) > 1e-30f ? 1.0f / dy : copysignf(1e30f, dy);
                 const float idz_ = fabsf(dz) > 1e-30f ? 1.0f / dz : copysignf(1e30f, dz);
@@ -403,9 +400,9 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                     const bool has = static_cast<uint32_t>(lane) < n && !(ANY && (tr.flags & 1u));
                     const uint32_t nx = c0 + 64u + static_cast<uint32_t>(lane);
                     const TriRec nxt = T[nx < cnt ? nx : 0u];                      // prefetch (uniformly skipped work is cheap)
-                    // conservative chunk test, step 1 (lanes = rays): which live rays' LINES miss the inflated chunk box, and
-                    // which of those are also outside the chunk's normal cone band (then no plane of the chunk is near-parallel)
-                    unsigned long long todo = live, guard_rays = 0ull;
+                    // conservative chunk test (lanes = rays): a live ray skips the chunk when no point of its line that a hit could
+                    // count at lies in the chunk's inflated box (rt_capi.cpp, build_chunk_bounds, has the error analysis)
+                    unsigned long long todo = live;
                     {
                         const ChunkBound bd = cbounds[c0 >> 6];
                         if (bd.sin_guard < 1.5f) {
@@ -419,23 +416,10 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                             // (t of an accepted hit lies in [tin, tout] up to ~1e-6 relative: its point is inside the padded box)
                             const bool miss = (tin > tout) || (tout < -1e-3f) ||
                                               (ANY ? (tin > 0.981f) : (tin > best_t + 1e-3f * (1.0f + fabsf(best_t))));
-                            const bool cone_safe = fabsf(dx * bd.ax + dy * bd.ay + dz * bd.az) > bd.pad0 * d_len;
-                            const unsigned long long boxmiss = __ballot(miss) & live;
-                            const unsigned long long culled = __ballot(miss && cone_safe) & live;
+                            const unsigned long long culled = __ballot(miss) & live;
                             todo = live & ~culled;
-                            guard_rays = boxmiss & ~culled;          // must pass the per-triangle guard to be skipped
                             RT_PROF_ADD(lane, 14, __popcll(culled));
                         }
-                    }
-                    // step 2 (lanes = triangles), rare: rays whose line misses the box but that may be near-parallel to some
-                    // plane of the chunk: skip only if |d.n| > tau |d| holds for EVERY triangle (near-parallel pairs make the
-                    // reference's t, hence its hit point, arbitrarily wrong and are always tested)
-                    while (guard_rays != 0ull) {
-                        const int r = static_cast<int>(__builtin_ctzll(guard_rays));
-                        guard_rays &= guard_rays - 1ull;
-                        const float dn = dot3(lane_f(dx, r), lane_f(dy, r), lane_f(dz, r), tr.nx, tr.ny, tr.nz);
-                        if (__ballot(has && !(fabsf(dn) > lane_f(guard_len, r))) == 0ull) { todo &= ~(1ull << r); RT_PROF_ADD(lane, 12, 1); }
-                        else RT_PROF_ADD(lane, 13, 1);
                     }
                     // step 3 (lanes = triangles): full test of the surviving rays, two rays per step for ILP (two independent
                     // division chains in flight)

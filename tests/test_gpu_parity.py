@@ -425,3 +425,68 @@ def test_error_paths_on_device(rt, scenes):
     assert lib.rt_create(C.byref(bad_ctx), 99) == c.RT_ERR_NO_DEVICE
     ctx.close()
     hs.close()
+@pytest.mark.gpu
+def test_chunk_culling_with_grazing_rays(rt, oracle, scenes):
+    """Adversarial cases for the chunk test: rays built to lie (almost) IN the plane of a mesh triangle -- angles from 1e-2 down
+    to 1e-8 rad and exactly in-plane, aimed through, beside and away from the triangle, closest-hit and shadow segments.  The
+    culled and the un-culled (RT_NO_CULL=1) walks must agree bit for bit: the cull may rely on no near-parallel guard."""
+    path = os.path.join(scenes, "dodgeColorTest.obj")
+    rng = np.random.default_rng(2024)
+    host = rt.HostScene(path, 1000, 15)
+    arr = host.arrays()
+    tv, fn = arr["tri_verts"].astype(np.float64), arr["face_normal"].astype(np.float64)
+    host.close()
+    nf = tv.shape[0]
+    m = 24000
+    f = rng.integers(0, nf, m)
+    A, B, Cc = tv[f, 0:3], tv[f, 3:6], tv[f, 6:9]
+    w = rng.random((m, 3)); w /= w.sum(1, keepdims=True)
+    target = w[:, :1] * A + w[:, 1:2] * B + w[:, 2:3] * Cc                       # a point of the triangle ...
+    target += (rng.random((m, 1)) < 0.3) * (B - A) * rng.normal(0, 2.0, (m, 1))   # ... or beside it, in its plane
+    inplane = (B - A) * rng.normal(0, 1, (m, 1)) + (Cc - A) * rng.normal(0, 1, (m, 1))
+    inplane /= np.maximum(np.linalg.norm(inplane, axis=1, keepdims=True), 1e-30)
+    ang = 10.0 ** rng.uniform(-8, -2, (m, 1)) * rng.choice([-1.0, 1.0], (m, 1))
+    ang[: m // 8] = 0.0                                                           # exactly in the plane
+    dirs = inplane + ang * fn[f]
+    dist = 10.0 ** rng.uniform(-2, 0.5, (m, 1))
+    o = (target - dirs * dist).astype(np.float32)
+    d = (dirs * dist * rng.choice([0.5, 1.0, 1.02, 2.0, 50.0], (m, 1))).astype(np.float32)   # hits at t ~ 2, 1, 0.98, 0.5, 0.02
+    hit_pts = (o.astype(np.float64) + d.astype(np.float64)).astype(np.float32)               # segment light=o -> hit point
+    for cap in (1000, 100):
+        res = []
+        for no_cull in (False, True):
+            if no_cull:
+                os.environ["RT_NO_CULL"] = "1"
+            else:
+                os.environ.pop("RT_NO_CULL", None)
+            fs = rt.Flyscene(scene_path=path)
+            fs.initialize(64, 64, True, False)
+            if cap != 1000:
+                fs.scene = rt.HostScene(path, cap, 15)
+                fs.ctx.upload(fs.scene)
+            fs.max_depth = 0
+            fs.traceRay(o, d)
+            face, t = fs.last_face.copy(), fs.last_t.copy()
+            vis = np.empty(m, np.uint8)
+            lib = fs.ctx.lib
+            rc = lib.rt_light_strikes(fs.ctx.handle, m, hit_pts.ctypes.data, o.ctypes.data, vis.ctypes.data)
+            assert rc == 0
+            res.append((face, t, vis.copy()))
+            fs.ctx.close()
+        os.environ.pop("RT_NO_CULL", None)
+        (fa, ta, va), (fb, tb, vb) = res
+        assert np.array_equal(fa, fb), (cap, int((fa != fb).sum()))
+        assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32)), cap
+        assert np.array_equal(va, vb), (cap, int((va != vb).sum()))
+        assert (fa >= 0).sum() > m // 10 and 0 < int(va.sum()) < m          # the batch exercises hits, misses, lit and shadowed
+        if cap == 1000:                                                     # and the culled walk agrees with the oracle
+            osc = oracle.load_scene(path, capacity=1000)
+            for i in range(0, m, 16):
+                of, ot = osc.closest_hit(o[i], d[i])
+                assert fa[i] == of, i
+                if of >= 0:
+                    assert np.float32(ta[i]) == np.float32(ot), i
+                _, ov = osc.light_strikes(hit_pts[i], o[i:i + 1])
+                assert bool(va[i]) == bool(ov[0]), i
+
+
