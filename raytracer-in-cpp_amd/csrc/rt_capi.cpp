@@ -408,7 +408,43 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
 
     free_scene(c);
     rt_status st;
-    if ((st = upload(c, &c->d_nodes, sc->nodes, sc->n_nodes)) != RT_OK) return st;
+    // device nodes = public nodes + content boxes, bottom-up (children always follow their parent in the array)
+    std::vector<DNode> dnodes(sc->n_nodes);
+    for (uint32_t ii = sc->n_nodes; ii-- > 0;) {
+        const rt_node &n = sc->nodes[ii];
+        DNode &dn = dnodes[ii];
+        std::memcpy(&dn, &n, sizeof(rt_node));
+        const uint32_t cnt = n.count_flags & 0x7fffffffu;
+        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {1e30f, 1e30f, 1e30f};      // nothing inside: a far-away point
+        bool any = false, open_box = false;
+        auto grow = [&](const float *l, const float *h) {
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = any ? std::fmin(lo[k], l[k]) : l[k];
+                hi[k] = any ? std::fmax(hi[k], h[k]) : h[k];
+            }
+            any = true;
+        };
+        if (n.count_flags & RT_NODE_LEAF) {
+            for (uint32_t k = 0; k < (cnt + 63u) / 64u; ++k) {
+                const ChunkBound &cb = cbs[leaf_chunk0[ii] + k];
+                if (cb.sin_guard >= 1.5f) open_box = true; else grow(cb.lo, cb.hi);
+            }
+        } else {
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const DNode &ch = dnodes[n.first + k];
+                if (ch.clo[0] <= -3e38f) open_box = true;
+                else if (!(ch.clo[0] >= 1e30f)) grow(ch.clo, ch.chi);
+            }
+        }
+        for (int k = 0; k < 3; ++k) {
+            const bool finite = std::isfinite(lo[k]) && std::isfinite(hi[k]);
+            dn.clo[k] = (open_box || !finite) ? -3e38f : lo[k];
+            dn.chi[k] = (open_box || !finite) ? 3e38f : hi[k];
+        }
+        if (open_box) { dn.clo[0] = dn.clo[1] = dn.clo[2] = -3e38f; dn.chi[0] = dn.chi[1] = dn.chi[2] = 3e38f; }
+        dn.pad[0] = dn.pad[1] = 0u;
+    }
+    if ((st = upload(c, &c->d_nodes, dnodes.data(), dnodes.size())) != RT_OK) return st;
     if ((st = upload(c, &c->d_tris, recs.data(), recs.size())) != RT_OK) return st;
     if ((st = upload(c, &c->d_chunks, cbs.data(), cbs.size())) != RT_OK) return st;
     if ((st = upload(c, &c->d_leaf_chunk0, leaf_chunk0.data(), leaf_chunk0.size())) != RT_OK) return st;
@@ -418,7 +454,7 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     if ((st = upload(c, &c->d_mat_id, sc->mat_id, sc->n_faces)) != RT_OK) return st;
     if ((st = upload(c, &c->d_vert_normal, sc->vert_normal, static_cast<size_t>(sc->n_vert_normals) * 3)) != RT_OK) return st;
     if ((st = upload(c, &c->d_mats, sc->materials, sc->n_materials)) != RT_OK) return st;
-    c->S.nodes = static_cast<const rt_node *>(c->d_nodes);
+    c->S.nodes = static_cast<const DNode *>(c->d_nodes);
     c->S.leaf_tris = static_cast<const TriRec *>(c->d_tris);
     c->S.chunks = static_cast<const ChunkBound *>(c->d_chunks);
     c->S.leaf_chunk0 = static_cast<const uint32_t *>(c->d_leaf_chunk0);
@@ -616,7 +652,7 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
     if (!counted) {
         std::fprintf(stderr, "RT_PROFILE ray-mode steps %llu useful %llu | tri-mode steps %llu useful %llu | box steps %llu useful %llu | leaves ray %llu tri %llu live-at-tri %llu | cone-culled pairs %llu guard-culled %llu guard-kept %llu\n",
                      h.prof[0], h.prof[1], h.prof[2], h.prof[3], h.prof[4], h.prof[5], h.prof[6], h.prof[7], h.prof[8], h.prof[14], h.prof[12], h.prof[13]);
-        std::fprintf(stderr, "RT_PROFILE plane cull: ray-mode triangles skipped %llu, tri-mode chunks skipped %llu\n", h.prof[64], h.prof[65]);
+        std::fprintf(stderr, "RT_PROFILE plane cull: ray-mode triangles skipped %llu, tri-mode chunks skipped %llu; content-box culled (ray,node) pairs %llu\n", h.prof[64], h.prof[65], h.prof[66]);
         std::fprintf(stderr, "RT_PROFILE shadow units %llu: cycles max %llu mean %.0f; log2 histogram:", h.prof[11], h.prof[9], h.prof[11] ? double(h.prof[10]) / double(h.prof[11]) : 0.0);
         for (int b = 8; b <= 30; ++b) std::fprintf(stderr, " [2^%d]=%llu", b, h.prof[16 + b]);
         std::fprintf(stderr, "\n");

@@ -101,8 +101,21 @@ enum : uint32_t {
     KIND_FRESNEL = 4     // illum 5:      fresnel * (0.15*phong + 0.85*child)  (flyscene.cpp:739-743)
 };
 
+// Device copy of a node: the public rt_node (the reference's box, used for the bit-exact boxIntersect) followed by the node's
+// CONTENT box -- the union of the inflated chunk boxes of every leaf below it (rt_capi.cpp, build_chunk_bounds), or
+// (-3e38, 3e38) when some chunk below is not cullable.  A ray whose line has no countable point inside the content box
+// cannot have an accepted hit anywhere in the subtree, whatever the reference's own box test says.  64 B = one
+// s_load_dwordx16 per child.
+struct alignas(16) DNode {
+    float bmin[3], bmax[3];
+    uint32_t first, count_flags;
+    float clo[3], chi[3];
+    uint32_t pad[2];
+};
+static_assert(sizeof(DNode) == 64, "DNode must be 64 bytes");
+
 struct DScene {
-    const rt_node *nodes;
+    const DNode *nodes;
     const TriRec *leaf_tris;
     const ChunkBound *chunks;          // per leaf: ceil(count/64) bounds starting at leaf_chunk0[node]
     const uint32_t *leaf_chunk0;

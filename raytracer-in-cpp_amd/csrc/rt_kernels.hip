@@ -315,7 +315,7 @@ __device__ unsigned long long *g_prof = nullptr;
 #define RT_COST_CHUNK_TEST 30u    // per chunk: conservative bound test for all 64 rays at once
 
 template <bool ANY, bool COUNT>
-__device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
+__device__ __forceinline__ void packet_walk(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris,
                                             const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                             const float extent, const WaveStack stk, const int lane, const WalkCtl wc, bool in_root,
                                             const float ox, const float oy, const float oz,      // ray origin
@@ -324,6 +324,12 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                                             const float brx, const float bry, const float brz,   // v_rcp_f32 of it (approximate)
                                             float &best_t, int &best_f, bool &occluded,
                                             uint32_t &cnt_box, uint32_t &cnt_ref) {
+    // per-ray quantities of the conservative box tests (content boxes of nodes, chunk boxes of big leaves); approximate
+    // arithmetic is fine, they only ever SKIP work
+    const float idx_ = fabsf(dx) > 1e-30f ? 1.0f / dx : copysignf(1e30f, dx);   // never inf: no inf*0 NaNs
+    const float idy_ = fabsf(dy) > 1e-30f ? 1.0f / dy : copysignf(1e30f, dy);
+    const float idz_ = fabsf(dz) > 1e-30f ? 1.0f / dz : copysignf(1e30f, dz);
+    const float slab_pad = 4e-4f * (fabsf(ox) + fabsf(oy) + fabsf(oz) + extent);
     int sp = 0;
     {
         unsigned long long m0 = __ballot(in_root);
@@ -343,7 +349,7 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
         if (ANY && !COUNT) mine = mine && !occluded;
         unsigned long long live = __ballot(mine);          // rays that still need this node
         if (live == 0ull) continue;
-        const rt_node nd = nodes[ni];
+        const DNode nd = nodes[ni];
         const uint32_t cnt = nd.count_flags & 0x7fffffffu;
         if (nd.count_flags & RT_NODE_LEAF) {
             if (COUNT && mine) cnt_ref += cnt;
@@ -389,10 +395,6 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
                 const ChunkBound *__restrict__ cbounds = chunks + leaf_chunk0[ni];
                 // per-ray quantities of the conservative chunk test (approximate arithmetic is fine: they only ever SKIP
                 // work); computed per leaf visit so that scenes that never take this mode (the cube) pay nothing
-                const float idx_ = fabsf(dx) > 1e-30f ? 1.0f / dx : copysignf(1e30f, dx);   // never inf: no inf*0 NaNs
-                const float idy_ = fabsf(dy) > 1e-30f ? 1.0f / dy : copysignf(1e30f, dy);
-                const float idz_ = fabsf(dz) > 1e-30f ? 1.0f / dz : copysignf(1e30f, dz);
-                const float slab_pad = 4e-4f * (fabsf(ox) + fabsf(oy) + fabsf(oz) + extent);
                 const uint32_t t_end = ce * 64u < cnt ? ce * 64u : cnt;
                 TriRec tr = T[cb * 64u + static_cast<uint32_t>(lane) < cnt ? cb * 64u + static_cast<uint32_t>(lane) : 0u];
                 for (uint32_t c0 = cb * 64u; c0 < t_end; c0 += 64u) {
@@ -546,8 +548,23 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
             RT_TILE_COUNT(stk, lane, 3, cnt);
             for (uint32_t c = 0; c < cnt; ++c) {
                 const uint32_t ci = nd.first + c;
-                const rt_node ch = nodes[ci];
-                const bool h = mine && box_hit_verified(ch.bmin, ox, oy, oz, bx, by, bz, brx, bry, brz);
+                const DNode ch = nodes[ci];
+                bool h = mine;
+                if (!COUNT) {
+                    // content test first (it is the cheaper one and rules out most children): no countable point of the line
+                    // inside the subtree's content box -> nothing below can be hit, whatever the reference's box test says
+                    const float t0x = (ch.clo[0] - slab_pad - ox) * idx_, t1x = (ch.chi[0] + slab_pad - ox) * idx_;
+                    const float t0y = (ch.clo[1] - slab_pad - oy) * idy_, t1y = (ch.chi[1] + slab_pad - oy) * idy_;
+                    const float t0z = (ch.clo[2] - slab_pad - oz) * idz_, t1z = (ch.chi[2] + slab_pad - oz) * idz_;
+                    const float tin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+                    const float tout = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+                    const bool miss = (tin > tout) || (tout < -1e-3f) ||
+                                      (ANY ? (tin > 0.981f) : (tin > best_t + 1e-3f * (1.0f + fabsf(best_t))));
+                    RT_PROF_ADD(lane, 66, __popcll(__ballot(h && miss)));
+                    h = h && !miss;
+                    if (__ballot(h) == 0ull) continue;
+                }
+                h = h && box_hit_verified(ch.bmin, ox, oy, oz, bx, by, bz, brx, bry, brz);   // BoundingBox::boxIntersect, exact
                 RT_PROF_ADD(lane, 4, 1); RT_PROF_ADD(lane, 5, __popcll(__ballot(mine)));
                 if (COUNT && mine) cnt_box += h ? 2u : 1u;
                 const unsigned long long hm = __ballot(h);
@@ -568,7 +585,7 @@ __device__ __forceinline__ void packet_walk(const rt_node *__restrict__ nodes, c
 struct LanePlane { float nx, ny, nz, nA; };
 
 template <bool ANY, bool COUNT>
-__device__ __forceinline__ void flat_walk(const rt_node &root, const TriRec *__restrict__ tris, bool in_root, const SegPacket &seg, const LanePlane &pl,
+__device__ __forceinline__ void flat_walk(const DNode &root, const TriRec *__restrict__ tris, bool in_root, const SegPacket &seg, const LanePlane &pl,
                                           const float ox, const float oy, const float oz,
                                           const float dx, const float dy, const float dz,
                                           float &best_t, int &best_f, bool &occluded, uint32_t &cnt_box, uint32_t &cnt_ref) {
@@ -637,7 +654,7 @@ __device__ __forceinline__ void flat_walk(const rt_node &root, const TriRec *__r
 }
 
 template <bool ANY, bool COUNT, bool FLAT>
-__device__ __forceinline__ void walk(const rt_node &root, const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
+__device__ __forceinline__ void walk(const DNode &root, const DNode *__restrict__ nodes, const TriRec *__restrict__ tris,
                                      const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                      const float extent, const WaveStack stk, const int lane, const WalkCtl wc, const LanePlane &pl, bool in_root,
                                      const float ox, const float oy, const float oz, const float dx, const float dy, const float dz,
@@ -713,7 +730,7 @@ __device__ __forceinline__ void light_sample(const DLights &L, const float px, c
 // and root-AABB cull of raytraceScene's serial loop (flyscene.cpp:573-598); otherwise reads compacted rays.
 // ======================================================================================================
 template <bool PRIMARY, bool COUNT, bool FLAT>
-__global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
+__global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris,
                                                           const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                                           const DScene S, const DCam *__restrict__ camp, const DLights L, const DFrame F,
                                                           const int level, const int ctr_slot,
@@ -728,7 +745,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const rt_node *__restri
     ShardMap rmap{0u, 0u, 0u, 0u};
     if (!PRIMARY) rmap = shard_map(ctl->n_rays[level], lane, 0xffffffffu, 1u, 64u);
     const uint32_t ntiles = PRIMARY ? static_cast<uint32_t>(F.tiles_x) * static_cast<uint32_t>(F.tiles_y) : rmap.total;
-    const rt_node root = nodes[0];
+    const DNode root = nodes[0];
     // the camera lives in device memory so that a captured hipGraph of the frame can be replayed with a new camera
     DCam cam;
     if (PRIMARY) cam = *camp;
@@ -878,7 +895,7 @@ struct TileRay {
 };
 
 template <bool PRIMARY>
-__device__ __forceinline__ TileRay tile_ray(const uint32_t tile, const int lane, const DFrame &F, const DCam &cam, const rt_node &root,
+__device__ __forceinline__ TileRay tile_ray(const uint32_t tile, const int lane, const DFrame &F, const DCam &cam, const DNode &root,
                                             const RayItem *__restrict__ rays_in, const ShardMap &rmap) {
     TileRay r;
     r.lx = r.ly = r.lz = 0.f; r.lmode = 0u;
@@ -919,7 +936,7 @@ __device__ __forceinline__ TileRay tile_ray(const uint32_t tile, const int lane,
 #define RT_NO_HIT_KEY 0xffffffffffffffffull
 
 template <bool PRIMARY, bool COUNT, int STAGE, bool CONT>
-__global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
+__global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris,
                                                           const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                                           const DScene S, const DCam *__restrict__ camp, const DLights L, const DFrame F,
                                                           const int level, const int lslots,
@@ -935,7 +952,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const rt_node *__restri
     ShardMap rmap{0u, 0u, 0u, 0u};
     if (!PRIMARY) rmap = shard_map(ctl->n_rays[level], lane, 0xffffffffu, 1u, 64u);
     const uint32_t ntiles = PRIMARY ? static_cast<uint32_t>(F.tiles_x) * static_cast<uint32_t>(F.tiles_y) : rmap.total;
-    const rt_node root = nodes[0];
+    const DNode root = nodes[0];
     DCam cam;
     if (PRIMARY) cam = *camp;
 
@@ -1081,7 +1098,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const rt_node *__restri
 #define RT_SHADOW_WPE 5
 #endif
 template <bool COUNT, bool FLAT, bool CONT>
-__global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(RT_SHADOW_WPE, 8))) void k_shadow(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
+__global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(RT_SHADOW_WPE, 8))) void k_shadow(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris,
                                                           const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                                            const DScene S, const DLights L, const int level, const int ctr_slot,
                                                            const int lslots, const uint32_t item_cap, const ShadeItem *__restrict__ items,
@@ -1098,7 +1115,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     const ShardMap imap = N <= 64u ? shard_map(ctl->n_items[level], lane, item_cap, static_cast<uint32_t>(lslots), G)
                                    : shard_map(ctl->n_items[level], lane, item_cap, static_cast<uint32_t>(lslots) * P, 1u);
     const unsigned long long units = imap.total;
-    const rt_node root = nodes[0];
+    const DNode root = nodes[0];
     const uint32_t slot = N <= 64u ? static_cast<uint32_t>(lane) / N : 0u;
     const uint32_t s_in = N <= 64u ? static_cast<uint32_t>(lane) - slot * N : static_cast<uint32_t>(lane);
     const unsigned long long low = N >= 64u ? ~0ull : ((1ull << N) - 1ull);
@@ -1457,7 +1474,7 @@ __global__ __launch_bounds__(256) void k_resolve(const DFrame F, const float4 *_
 // ======================================================================================================
 // lightStrikes on explicit segments (rt_light_strikes): lane = segment light[i] -> hit[i]
 // ======================================================================================================
-__global__ __launch_bounds__(RT_WAVES * 64) void k_segments(const rt_node *__restrict__ nodes, const TriRec *__restrict__ tris,
+__global__ __launch_bounds__(RT_WAVES * 64) void k_segments(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris,
                                                           const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                                              const DScene S, const int n, const float *__restrict__ hit,
                                                              const float *__restrict__ light, uint8_t *__restrict__ vis) {
@@ -1466,7 +1483,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_segments(const rt_node *__res
     __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, s_stage + wave * RT_STAGE_TRIS * 5};
-    const rt_node root = nodes[0];
+    const DNode root = nodes[0];
     const int waves_total = gridDim.x * RT_WAVES;
     for (int base = (blockIdx.x * RT_WAVES + wave) * 64; base < n; base += waves_total * 64) {
         const int i = base + lane;
