@@ -10,10 +10,10 @@ run() { # label, env...
   python -c "
 import json; d=json.load(open('gpurun_out/bench_$label.json')); print('$label', d['ms_per_step'], 'ms', d['roofline']['ms_per_frame']['instrumented_frame'])"
 }
-for b in 500 1000 1500 2000 3000; do
-  run b$b RT_STAGED_TRACE=1 RT_TRACE_BUDGET=$b RT_SHADOW_BUDGET=$b
+for b in 0 750 1500 3000 6000; do
+  run sb$b RT_SHADOW_BUDGET=$b
 done
-run b1500_t750 RT_STAGED_TRACE=1 RT_TRACE_BUDGET=1500 RT_SHADOW_BUDGET=1500 RT_TASK_TARGET=750
-run b3000_t1000 RT_STAGED_TRACE=1 RT_TRACE_BUDGET=3000 RT_SHADOW_BUDGET=3000 RT_TASK_TARGET=1000
-run b1000_t2000 RT_STAGED_TRACE=1 RT_TRACE_BUDGET=1000 RT_SHADOW_BUDGET=1000 RT_TASK_TARGET=2000
-run fused_sh1500 RT_STAGED_TRACE=0 RT_SHADOW_BUDGET=1500
+for b in 0 500 2000 4000; do
+  run tb$b RT_TRACE_BUDGET=$b
+done
+run fused RT_STAGED_TRACE=0

@@ -1,0 +1,22 @@
+#!/bin/bash
+# VALU wave-instructions per launch of the bench kernels (SQ_INSTS_VALU, its own PMC pass): tools/valu.sh <scene> [bench args]
+sc=${1:-cube}; shift 1
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+mkdir -p $R/gpurun_out/valu_$sc
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE -d $R/gpurun_out/valu_$sc/a -o a --output-format csv -- python3 $R/bench.py --scene $sc --steps 2 --warmup 1 --no-cpu-baseline "$@" > $R/gpurun_out/valu_$sc/a.log 2>&1
+python3 - <<PY
+import csv, collections, glob, json
+per = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$R/gpurun_out/valu_$sc/a/*counter_collection.csv"):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "rtamd" in k: per[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+out = {}
+for k, d in per.items():
+    i = max(range(len(d["SQ_INSTS_VALU"])), key=lambda j: d["SQ_INSTS_VALU"][j])     # the heaviest (level-0) launch
+    out[k] = {"valu_wave_instructions": d["SQ_INSTS_VALU"][i], "salu_wave_instructions": d["SQ_INSTS_SALU"][i], "waves": d["SQ_WAVES"][i],
+              "gpu_cycles": d["GRBM_GUI_ACTIVE"][i] / 8.0, "launches": len(d["SQ_INSTS_VALU"])}
+    print(k, out[k])
+json.dump(out, open("$R/gpurun_out/valu_$sc/valu_$sc.json", "w"), indent=1)
+PY
