@@ -713,16 +713,22 @@ __device__ __forceinline__ uint32_t shard_reserve(uint32_t *counters, const uint
 }
 
 // arealight::getPointLights / createSpherePoint (arealight.hpp:15-25, flyscene.cpp:956-972): sample s of light p
-__device__ __forceinline__ void light_sample(const DLights &L, const float px, const float py, const float pz, const int s,
-                                             float &sx, float &sy, float &sz) {
+// (i, j) = (s / vsteps, s % vsteps) given as the floats i + 0.5 and j + 0.5: the callers keep them out of their hot loops
+// (an integer division by a run-time value costs ~25 VALU instructions)
+__device__ __forceinline__ void light_sample_ij(const DLights &L, const float px, const float py, const float pz, const float fi, const float fj,
+                                                float &sx, float &sy, float &sz) {
     if (L.mode == RT_LIGHT_POINT) { sx = px; sy = py; sz = pz; return; }
     const float ux = px + L.len_x * 1.0f;     // uvec = corner + lengthX * (1,0,0)
     const float uz = pz + L.len_x * 0.0f;
     const float vy = py + L.len_y * 1.0f;     // vvec = corner + lengthY * (0,1,0)
-    const int i = s / L.vsteps, j = s - i * L.vsteps;
-    sx = (static_cast<float>(i) + 0.5f) * (ux / static_cast<float>(L.usteps));
-    sy = (static_cast<float>(j) + 0.5f) * (vy / static_cast<float>(L.vsteps));
+    sx = fi * (ux / static_cast<float>(L.usteps));
+    sy = fj * (vy / static_cast<float>(L.vsteps));
     sz = uz;
+}
+__device__ __forceinline__ void light_sample(const DLights &L, const float px, const float py, const float pz, const int s,
+                                             float &sx, float &sy, float &sz) {
+    const int i = s / L.vsteps, j = s - i * L.vsteps;
+    light_sample_ij(L, px, py, pz, static_cast<float>(i) + 0.5f, static_cast<float>(j) + 0.5f, sx, sy, sz);
 }
 
 // ======================================================================================================
@@ -1119,6 +1125,10 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     const uint32_t slot = N <= 64u ? static_cast<uint32_t>(lane) / N : 0u;
     const uint32_t s_in = N <= 64u ? static_cast<uint32_t>(lane) - slot * N : static_cast<uint32_t>(lane);
     const unsigned long long low = N >= 64u ? ~0ull : ((1ull << N) - 1ull);
+    // sample grid coordinates of this lane: fixed for the whole kernel when a unit holds all N <= 64 samples
+    const uint32_t vst = static_cast<uint32_t>(L.vsteps > 0 ? L.vsteps : 1);
+    const float fi_lane = static_cast<float>(s_in / vst) + 0.5f, fj_lane = static_cast<float>(s_in % vst) + 0.5f;
+    const float fi_last = static_cast<float>(L.usteps - 1) + 0.5f, fj_last = static_cast<float>(L.vsteps - 1) + 0.5f;
 
     LanePlane plane{0.f, 0.f, 0.f, 0.f};
     if (FLAT && static_cast<uint32_t>(lane) < (root.count_flags & 0x7fffffffu)) {
@@ -1171,7 +1181,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
             g = lu / P; pass = lu - g * P; s = pass * 64u + s_in;
             valid = s < N;
         }
-        const uint32_t item_i = valid ? g / static_cast<uint32_t>(lslots) : 0u;
+        const uint32_t item_i = valid ? (lslots == 1 ? g : g / static_cast<uint32_t>(lslots)) : 0u;
         const int l = valid ? static_cast<int>(g - item_i * static_cast<uint32_t>(lslots)) : 0;
         const ShadeItem it = items[sh * item_cap + item_i];
         g += sh * item_cap * static_cast<uint32_t>(lslots);               // (item storage index) * lslots + light: the vis slot
@@ -1180,15 +1190,16 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
         const float hx = it.ox + it.t * it.dx, hy = it.oy + it.t * it.dy, hz = it.oz + it.t * it.dz;
         const float px = it.lmode ? it.lx : L.pos[l][0], py = it.lmode ? it.ly : L.pos[l][1], pz = it.lmode ? it.lz : L.pos[l][2];
         float sx, sy, sz;
-        light_sample(L, px, py, pz, static_cast<int>(s), sx, sy, sz);
+        if (N <= 64u) light_sample_ij(L, px, py, pz, fi_lane, fj_lane, sx, sy, sz);
+        else light_sample(L, px, py, pz, static_cast<int>(s), sx, sy, sz);
         const float ddx = hx - sx, ddy = hy - sy, ddz = hz - sz;
         const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
         if (plane_cull) {
             // box of this light's sample positions: light_sample is monotone in each sample index, so its first and last
             // index give the exact extremes
             float x0, x1, y0, y1, z0, z1;
-            light_sample(L, px, py, pz, 0, x0, y0, z0);
-            light_sample(L, px, py, pz, L.n_samples - 1, x1, y1, z1);
+            light_sample_ij(L, px, py, pz, 0.5f, 0.5f, x0, y0, z0);
+            light_sample_ij(L, px, py, pz, fi_last, fj_last, x1, y1, z1);
             wc.seg.on = true;
             wc.seg.hx = hx; wc.seg.hy = hy; wc.seg.hz = hz;
             wc.seg.slx = fminf(x0, x1); wc.seg.shx = fmaxf(x0, x1);
@@ -1359,13 +1370,16 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
                 // so two samples' independent sqrt/divide chains can be in flight (ILP at 3 waves per SIMD).
                 const float lkd0 = L.color[0] * mat.kd[0], lkd1 = L.color[1] * mat.kd[1], lkd2 = L.color[2] * mat.kd[2];
                 const float lks0 = L.color[0] * mat.ks[0], lks1 = L.color[1] * mat.ks[1], lks2 = L.color[2] * mat.ks[2];
+                uint32_t si = 0, sj = 0;                       // s = si * vsteps + sj, kept as counters: no division per sample
+                const uint32_t vst = static_cast<uint32_t>(L.vsteps > 0 ? L.vsteps : 1);
 #pragma unroll 2
                 for (uint32_t s = 0; s < N; ++s) {
                     if ((s & 63u) == 0u) word = vw[s >> 6];
                     const bool visible = ((word >> (s & 63u)) & 1ull) != 0ull;
                     sum += visible ? 1.0f : 0.0f;
                     float sx, sy, sz;
-                    light_sample(L, px, py, pz, static_cast<int>(s), sx, sy, sz);
+                    light_sample_ij(L, px, py, pz, static_cast<float>(si) + 0.5f, static_cast<float>(sj) + 0.5f, sx, sy, sz);
+                    if (++sj == vst) { sj = 0; ++si; }
                     float ldx = sx - hx, ldy = sy - hy, ldz = sz - hz;
                     normalize3(ldx, ldy, ldz);
                     const float ldn = dot3(ldx, ldy, ldz, nx, ny, nz);
