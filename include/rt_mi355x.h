@@ -200,6 +200,9 @@ void rt_default_lights(rt_lights *l, int32_t area);
 /* replaces: Tucano::ImageImporter::writePPMImage (ppmIO.hpp:130-151): byte-exact ASCII P3                         */
 rt_status rt_write_ppm(const char *path, const float *rgb, int32_t width, int32_t height);
 rt_status rt_write_ppm_u8(const char *path, const uint8_t *rgb8, int32_t width, int32_t height);
+/* binary side channel beside result.ppm (no reference counterpart): PFM "PF\nW H\n-1.0\n" + little-endian
+ * float RGB rows, bottom row first as the format demands -- the un-quantised frame, 12 bytes per pixel                     */
+rt_status rt_write_pfm(const char *path, const float *rgb, int32_t width, int32_t height);
 
 #ifdef __cplusplus
 }

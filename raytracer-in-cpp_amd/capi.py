@@ -100,6 +100,7 @@ _SIGNATURES = [
     ("rt_default_lights", None, [_P(rt_lights), C.c_int32]),
     ("rt_write_ppm", C.c_int, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]),
     ("rt_write_ppm_u8", C.c_int, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]),
+    ("rt_write_pfm", C.c_int, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 

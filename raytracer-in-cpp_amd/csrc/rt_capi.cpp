@@ -993,6 +993,16 @@ extern "C" rt_status rt_write_ppm(const char *path, const float *rgb, int32_t w,
     if (!path || !rgb || w <= 0 || h <= 0) return RT_ERR_INVALID;
     return write_ppm(path, rgb, w, h) ? RT_OK : RT_ERR_IO;
 }
+extern "C" rt_status rt_write_pfm(const char *path, const float *rgb, int32_t w, int32_t h) {
+    if (!path || !rgb || w <= 0 || h <= 0) return RT_ERR_INVALID;
+    std::FILE *f = std::fopen(path, "wb");
+    if (!f) return RT_ERR_IO;
+    bool ok = std::fprintf(f, "PF\n%d %d\n-1.0\n", w, h) > 0;
+    for (int32_t y = h - 1; ok && y >= 0; --y)
+        ok = std::fwrite(rgb + static_cast<size_t>(y) * w * 3, sizeof(float), static_cast<size_t>(w) * 3, f) == static_cast<size_t>(w) * 3;
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? RT_OK : RT_ERR_IO;
+}
 extern "C" rt_status rt_write_ppm_u8(const char *path, const uint8_t *rgb, int32_t w, int32_t h) {
     if (!path || !rgb || w <= 0 || h <= 0) return RT_ERR_INVALID;
     return write_ppm_u8(path, rgb, w, h) ? RT_OK : RT_ERR_IO;

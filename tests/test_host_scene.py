@@ -116,6 +116,21 @@ def test_ppm_writer_byte_exact(rt, oracle, scenes, tmp_path):
     osc.close()
 
 
+def test_pfm_side_channel_round_trips(rt, tmp_path):
+    import ctypes as C
+    rng = np.random.default_rng(8)
+    rgb = rng.random((19, 31, 3), dtype=np.float32) * 1.5
+    lib = rt.load_library()
+    p = tmp_path / "a.pfm"
+    assert lib.rt_write_pfm(str(p).encode(), rgb.ctypes.data_as(C.c_void_p), 31, 19) == 0
+    raw = p.read_bytes()
+    head = b"PF\n31 19\n-1.0\n"
+    assert raw.startswith(head) and len(raw) == len(head) + 19 * 31 * 12
+    back = np.frombuffer(raw[len(head):], dtype="<f4").reshape(19, 31, 3)[::-1]
+    assert np.array_equal(back.view(np.uint32), rgb.view(np.uint32))
+    assert lib.rt_write_pfm(b"/nonexistent_dir/x.pfm", rgb.ctypes.data_as(C.c_void_p), 31, 19) == rt.capi.RT_ERR_IO
+
+
 def test_bad_inputs_are_rejected(rt, scenes, tmp_path):
     import ctypes as C
     lib = rt.load_library()
