@@ -324,11 +324,11 @@ __device__ __forceinline__ void packet_walk(const DNode *__restrict__ nodes, con
                                             const float brx, const float bry, const float brz,   // v_rcp_f32 of it (approximate)
                                             float &best_t, int &best_f, bool &occluded,
                                             uint32_t &cnt_box, uint32_t &cnt_ref) {
-    // per-ray quantities of the conservative box tests (content boxes of nodes, chunk boxes of big leaves); approximate
-    // arithmetic is fine, they only ever SKIP work
-    const float idx_ = fabsf(dx) > 1e-30f ? 1.0f / dx : copysignf(1e30f, dx);   // never inf: no inf*0 NaNs
-    const float idy_ = fabsf(dy) > 1e-30f ? 1.0f / dy : copysignf(1e30f, dy);
-    const float idz_ = fabsf(dz) > 1e-30f ? 1.0f / dz : copysignf(1e30f, dz);
+    // The conservative box tests (content boxes of nodes, chunk boxes of big leaves) only ever SKIP work, so approximate
+    // arithmetic is fine: they use the v_rcp_f32 reciprocals of the box-test direction that the caller already holds (it is the
+    // triangle-test direction up to one rounding).  A zero component gives inf: an origin inside that slab yields (-inf, +inf) = no
+    // constraint, one outside yields tin = +inf = miss (both correct for a line parallel to the slab), 0 * inf = NaN keeps the box.
+    const float idx_ = brx, idy_ = bry, idz_ = brz;
     const float slab_pad = 4e-4f * (fabsf(ox) + fabsf(oy) + fabsf(oz) + extent);
     int sp = 0;
     {
