@@ -713,17 +713,31 @@ __device__ __forceinline__ uint32_t shard_reserve(uint32_t *counters, const uint
 }
 
 // arealight::getPointLights / createSpherePoint (arealight.hpp:15-25, flyscene.cpp:956-972): sample s of light p
-// (i, j) = (s / vsteps, s % vsteps) given as the floats i + 0.5 and j + 0.5: the callers keep them out of their hot loops
-// (an integer division by a run-time value costs ~25 VALU instructions)
-__device__ __forceinline__ void light_sample_ij(const DLights &L, const float px, const float py, const float pz, const float fi, const float fj,
-                                                float &sx, float &sy, float &sz) {
-    if (L.mode == RT_LIGHT_POINT) { sx = px; sy = py; sz = pz; return; }
+// The sample grid of one light: sample (i, j) = ((i + 0.5) * cx, (j + 0.5) * cy, z).  cx and cy each hold a float division, so a
+// caller that needs several samples of the same light (k_shadow: the lane's sample + the two corners of the sample box) builds
+// the grid once; (i, j) = (s / vsteps, s % vsteps) are passed as the floats i + 0.5 and j + 0.5, which the callers keep out of
+// their hot loops (an integer division by a run-time value costs ~25 VALU instructions).
+struct LightGrid { float cx, cy, z, px, py; bool point; };
+__device__ __forceinline__ LightGrid light_grid(const DLights &L, const float px, const float py, const float pz) {
+    LightGrid g;
+    g.point = L.mode == RT_LIGHT_POINT;
+    g.px = px; g.py = py;
     const float ux = px + L.len_x * 1.0f;     // uvec = corner + lengthX * (1,0,0)
     const float uz = pz + L.len_x * 0.0f;
     const float vy = py + L.len_y * 1.0f;     // vvec = corner + lengthY * (0,1,0)
-    sx = fi * (ux / static_cast<float>(L.usteps));
-    sy = fj * (vy / static_cast<float>(L.vsteps));
-    sz = uz;
+    g.cx = ux / static_cast<float>(L.usteps);
+    g.cy = vy / static_cast<float>(L.vsteps);
+    g.z = g.point ? pz : uz;
+    return g;
+}
+__device__ __forceinline__ void grid_sample(const LightGrid &g, const float fi, const float fj, float &sx, float &sy, float &sz) {
+    sx = g.point ? g.px : fi * g.cx;
+    sy = g.point ? g.py : fj * g.cy;
+    sz = g.z;
+}
+__device__ __forceinline__ void light_sample_ij(const DLights &L, const float px, const float py, const float pz, const float fi, const float fj,
+                                                float &sx, float &sy, float &sz) {
+    grid_sample(light_grid(L, px, py, pz), fi, fj, sx, sy, sz);
 }
 __device__ __forceinline__ void light_sample(const DLights &L, const float px, const float py, const float pz, const int s,
                                              float &sx, float &sy, float &sz) {
@@ -1190,16 +1204,17 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
         const float hx = it.ox + it.t * it.dx, hy = it.oy + it.t * it.dy, hz = it.oz + it.t * it.dz;
         const float px = it.lmode ? it.lx : L.pos[l][0], py = it.lmode ? it.ly : L.pos[l][1], pz = it.lmode ? it.lz : L.pos[l][2];
         float sx, sy, sz;
-        if (N <= 64u) light_sample_ij(L, px, py, pz, fi_lane, fj_lane, sx, sy, sz);
-        else light_sample(L, px, py, pz, static_cast<int>(s), sx, sy, sz);
+        const LightGrid lg = light_grid(L, px, py, pz);
+        if (N <= 64u) grid_sample(lg, fi_lane, fj_lane, sx, sy, sz);
+        else grid_sample(lg, static_cast<float>(s / vst) + 0.5f, static_cast<float>(s % vst) + 0.5f, sx, sy, sz);
         const float ddx = hx - sx, ddy = hy - sy, ddz = hz - sz;
         const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
         if (plane_cull) {
             // box of this light's sample positions: light_sample is monotone in each sample index, so its first and last
             // index give the exact extremes
             float x0, x1, y0, y1, z0, z1;
-            light_sample_ij(L, px, py, pz, 0.5f, 0.5f, x0, y0, z0);
-            light_sample_ij(L, px, py, pz, fi_last, fj_last, x1, y1, z1);
+            grid_sample(lg, 0.5f, 0.5f, x0, y0, z0);
+            grid_sample(lg, fi_last, fj_last, x1, y1, z1);
             wc.seg.on = true;
             wc.seg.hx = hx; wc.seg.hy = hy; wc.seg.hz = hz;
             wc.seg.slx = fminf(x0, x1); wc.seg.shx = fmaxf(x0, x1);
@@ -1370,6 +1385,7 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
                 // so two samples' independent sqrt/divide chains can be in flight (ILP at 3 waves per SIMD).
                 const float lkd0 = L.color[0] * mat.kd[0], lkd1 = L.color[1] * mat.kd[1], lkd2 = L.color[2] * mat.kd[2];
                 const float lks0 = L.color[0] * mat.ks[0], lks1 = L.color[1] * mat.ks[1], lks2 = L.color[2] * mat.ks[2];
+                const LightGrid lg = light_grid(L, px, py, pz);
                 uint32_t si = 0, sj = 0;                       // s = si * vsteps + sj, kept as counters: no division per sample
                 const uint32_t vst = static_cast<uint32_t>(L.vsteps > 0 ? L.vsteps : 1);
 #pragma unroll 2
@@ -1378,7 +1394,7 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
                     const bool visible = ((word >> (s & 63u)) & 1ull) != 0ull;
                     sum += visible ? 1.0f : 0.0f;
                     float sx, sy, sz;
-                    light_sample_ij(L, px, py, pz, static_cast<float>(si) + 0.5f, static_cast<float>(sj) + 0.5f, sx, sy, sz);
+                    grid_sample(lg, static_cast<float>(si) + 0.5f, static_cast<float>(sj) + 0.5f, sx, sy, sz);
                     if (++sj == vst) { sj = 0; ++si; }
                     float ldx = sx - hx, ldy = sy - hy, ldz = sz - hz;
                     normalize3(ldx, ldy, ldz);
