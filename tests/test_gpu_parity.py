@@ -426,6 +426,30 @@ def test_error_paths_on_device(rt, scenes):
     ctx.close()
     hs.close()
 @pytest.mark.gpu
+def test_plane_culling_is_exact_on_flat_scenes(rt, oracle, scenes):
+    """cube.obj (one leaf: the FLAT kernels): per-unit plane culling of k_shadow, with the per-triangle constants prepared
+    for the scene light and with per-unit boxes on the bounce levels (mirror cube: lmode items), against RT_NO_CULL=1 --
+    bit-identical float frames for several light grids, sizes and a yawed camera."""
+    path = os.path.join(scenes, "cube.obj")
+    for (w, h, u, v, depth, yaw) in [(640, 360, 8, 8, 4, 0.0), (320, 320, 5, 5, 3, 0.7), (333, 211, 16, 16, 2, -1.1), (256, 256, 1, 1, 4, 0.2)]:
+        frames = []
+        for no_cull in (False, True):
+            if no_cull:
+                os.environ["RT_NO_CULL"] = "1"
+            else:
+                os.environ.pop("RT_NO_CULL", None)
+            fs = rt.Flyscene(scene_path=path)
+            fs.initialize(w, h, True, u == 1)
+            fs.usteps, fs.vsteps, fs.max_depth = u, v, depth
+            if yaw:
+                fs.camera = rt.default_camera(w, h, yaw)
+            frames.append(fs.raytraceScene(w, h, write_ppm=False).copy())
+            fs.ctx.close()
+        os.environ.pop("RT_NO_CULL", None)
+        assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32)), (w, h, u, v, depth, yaw)
+
+
+@pytest.mark.gpu
 def test_chunk_culling_with_grazing_rays(rt, oracle, scenes):
     """Adversarial cases for the chunk test: rays built to lie (almost) IN the plane of a mesh triangle -- angles from 1e-2 down
     to 1e-8 rad and exactly in-plane, aimed through, beside and away from the triangle, closest-hit and shadow segments.  The
