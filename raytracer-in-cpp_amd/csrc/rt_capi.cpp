@@ -123,6 +123,7 @@ extern "C" rt_status rt_create(rt_ctx **out, int device) {
     if (const char *dt = std::getenv("RT_TRACE_DYNAMIC")) c->dyn_trace = std::atoi(dt) != 0;
     if (const char *sb = std::getenv("RT_SHADOW_BUDGET")) c->shadow_budget = static_cast<uint32_t>(std::atoi(sb));
     if (const char *sg = std::getenv("RT_STAGED_TRACE")) c->staged_trace = std::atoi(sg) != 0;
+    if (const char *tc = std::getenv("RT_TASK_CAP")) { const long v = std::atol(tc); if (v >= 64 && v <= (1l << 24)) c->task_cap = static_cast<uint32_t>(v); }
     if (const char *tt = std::getenv("RT_TASK_TARGET")) c->task_target = static_cast<uint32_t>(std::atoi(tt));
     if (const char *tb = std::getenv("RT_TRACE_BUDGET")) c->trace_budget = static_cast<uint32_t>(std::atoi(tb));
     if (const char *gm = std::getenv("RT_GRID_MULT")) {          // tuning knob: grid = CUs x residency x mult
@@ -640,10 +641,19 @@ static rt_status sum_frame_times(rt_ctx *c, size_t ev, int levels_run, rt_stats 
     return RT_OK;
 }
 
+// after a synchronise: did a kernel of the last frame fail to reserve list space?  (never expected; see list_cap)
+static rt_status check_overflow(rt_ctx *c) {
+    uint32_t ov = 0;
+    HIPCHK(c, hipMemcpy(&ov, &c->d_ctl->overflow, sizeof ov, hipMemcpyDeviceToHost));
+    if (ov) { c->err = "internal: a compaction list overflowed its capacity; the frame is incomplete"; return RT_ERR_HIP; }
+    return RT_OK;
+}
+
 static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int levels_run, bool timed, rt_stats *out, bool counted) {
     HIPCHK(c, hipStreamSynchronize(st));
     Control h;
     HIPCHK(c, hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
+    if (h.overflow) { c->err = "internal: a compaction list overflowed its capacity; the frame is incomplete"; return RT_ERR_HIP; }
     fold_stats(h);
     if (std::getenv("RT_DEBUG")) std::fprintf(stderr, "RT_DEBUG level0: items %u tasks closest %u %u centre %u %u shadow %u %u\n", [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_items[0][sh * 16]; return t; }(), h.n_tasks[0][0], 0u, h.n_tasks[0][1], 0u, h.n_tasks[0][2], 0u);
     out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample;
@@ -833,6 +843,7 @@ extern "C" rt_status rt_timing_collect(rt_ctx *c, rt_stats *out) {
     HIPCHK(c, hipStreamSynchronize(c->pending_stream));
     Control h;
     HIPCHK(c, hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
+    if (h.overflow) { c->err = "internal: a compaction list overflowed its capacity; a frame is incomplete"; return RT_ERR_HIP; }
     fold_stats(h);
     out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample;
     out->pixels = c->pending_frame.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;
@@ -864,6 +875,7 @@ extern "C" rt_status rt_render(rt_ctx *c, const rt_camera *cam, const rt_lights 
     rt_status s = rt_render_device(c, cam, lights, p, c->d_rgb, nullptr, out_hit ? c->d_hit : nullptr, nullptr, stats);
     if (s != RT_OK) return s;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((s = check_overflow(c)) != RT_OK) return s;
     if (npix) {
         HIPCHK(c, hipMemcpy(out_rgb, c->d_rgb, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
         if (out_hit) HIPCHK(c, hipMemcpy(out_hit, c->d_hit, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -911,6 +923,7 @@ extern "C" rt_status rt_trace_rays(rt_ctx *c, const rt_lights *lights, int32_t m
     HIPCHK(c, hipMemcpyAsync(c->d_rays[0], rays.data(), need * sizeof(RayItem), hipMemcpyHostToDevice, c->stream));
     if ((s = run_frame(c, c->stream, nullptr, L, F, false, false, c->d_rgb, nullptr, c->d_hit, c->d_t, 0, static_cast<uint32_t>(n))) != RT_OK) return s;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((s = check_overflow(c)) != RT_OK) return s;
     HIPCHK(c, hipMemcpy(out_rgb, c->d_rgb, need * 3 * sizeof(float), hipMemcpyDeviceToHost));
     if (out_face) HIPCHK(c, hipMemcpy(out_face, c->d_hit, need * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (out_t) HIPCHK(c, hipMemcpy(out_t, c->d_t, need * sizeof(float), hipMemcpyDeviceToHost));

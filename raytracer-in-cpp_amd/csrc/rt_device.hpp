@@ -176,6 +176,8 @@ struct Control {
     uint32_t n_items[RT_MAX_DEPTH + 1][RT_LIST_SHARDS * 16];   // lit hits per level and shard (counter s at [s * 16])
     uint32_t n_rays[RT_MAX_DEPTH + 2][RT_LIST_SHARDS * 16];    // bounce rays per level and shard (n_rays[0][0] = rt_trace_rays input count)
     uint32_t n_tasks[RT_MAX_DEPTH + 1][4];           // leaf tasks per level: closest q0 | centre q1 | shadow q2 | (spare)
+    uint32_t overflow;                               // set by a kernel whose list reservation did not fit (never expected: the
+                                                     // capacities are derived from the tile counts); the host turns it into an error
     // totals, filled on the HOST by fold_stats() from the sharded counters below
     unsigned long long rays_primary, rays_bounce, rays_centre, rays_sample, pixels_culled, shaded_hits;
     unsigned long long box_tests, leaf_tri_refs;              // k_trace (closest hit + light-centre rays)

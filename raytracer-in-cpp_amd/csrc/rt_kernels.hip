@@ -393,18 +393,20 @@ __device__ __forceinline__ void packet_walk(const DNode *__restrict__ nodes, con
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(wc.task_count, ntask);
                 base = uniform_u32(base);
-                if (base + ntask <= wc.task_cap) {
-                    for (uint32_t i = static_cast<uint32_t>(lane); i < ntask; i += 64u) {
-                        ContTask t;
-                        t.unit = wc.unit; t.node = ni; t.mask = live;
-                        t.c_begin = static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * i / ntask);
-                        t.c_end = static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * (i + 1u) / ntask);
-                        t.pad0 = t.pad1 = 0u;
-                        wc.tasks[base + i] = t;
-                    }
-                    continue;
+                // The counter only ever grows (the consumer clamps it to the capacity): pieces that fall past the end of the
+                // queue are simply processed here.  (Giving a failed reservation back with an atomicSub is unsound: a later
+                // reservation can land inside the window and end up beyond the final count.)
+                const uint32_t fit = base >= wc.task_cap ? 0u : (ntask < wc.task_cap - base ? ntask : wc.task_cap - base);
+                for (uint32_t i = static_cast<uint32_t>(lane); i < fit; i += 64u) {
+                    ContTask t;
+                    t.unit = wc.unit; t.node = ni; t.mask = live;
+                    t.c_begin = static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * i / ntask);
+                    t.c_end = static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * (i + 1u) / ntask);
+                    t.pad0 = t.pad1 = 0u;
+                    wc.tasks[base + i] = t;
                 }
-                if (lane == 0) atomicSub(wc.task_count, ntask);   // queue full: process inline
+                if (fit == ntask) continue;
+                cb = static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * fit / ntask);       // the rest of the leaf, inline
             }
             RT_PROF_ADD(lane, tri_mode ? 7 : 6, 1);
             RT_TILE_COUNT(stk, lane, tri_mode ? 1 : 0, cnt);
@@ -724,13 +726,14 @@ __device__ __forceinline__ void shard_find(const ShardMap &m, const uint32_t w, 
     cnt = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(m.cnt), static_cast<int>(shard)));
 }
 // one returning atomic per wave on the counter of the list shard picked by the producing tile / group number
-__device__ __forceinline__ uint32_t shard_reserve(uint32_t *counters, const uint32_t producer, const uint32_t n, const uint32_t cap, const int lane,
-                                                  bool &fits) {
+__device__ __forceinline__ uint32_t shard_reserve(uint32_t *counters, uint32_t *overflow, const uint32_t producer, const uint32_t n, const uint32_t cap,
+                                                  const int lane, bool &fits) {
     const uint32_t sh = producer & (RT_LIST_SHARDS - 1u);
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&counters[sh * 16u], n);
     base = uniform_u32(base);
-    fits = base + n <= cap;       // always true: the capacity is derived from the tile count (rt_capi.cpp, list_caps)
+    fits = base + n <= cap;       // always true: the capacity is derived from the tile count (rt_capi.cpp, list_cap)
+    if (!fits && lane == 0) atomicOr(overflow, 1u);      // ... and if it ever is not, the frame is reported as failed, not silently short
     return sh * cap + base;
 }
 
@@ -881,7 +884,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const DNode *__restrict
         const unsigned long long lm = __ballot(lit);
         if (lm != 0ull) {
             bool fits;
-            const uint32_t base = shard_reserve(ctl->n_items[level], tile, static_cast<uint32_t>(__popcll(lm)), F.item_cap, lane, fits);
+            const uint32_t base = shard_reserve(ctl->n_items[level], &ctl->overflow, tile, static_cast<uint32_t>(__popcll(lm)), F.item_cap, lane, fits);
             if (lit && fits) {
                 ShadeItem o;
                 o.ox = ox; o.oy = oy; o.oz = oz; o.dx = dx; o.dy = dy; o.dz = dz;
@@ -1100,7 +1103,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
                 const unsigned long long lm = __ballot(is_lit);
                 if (lm != 0ull) {
                     bool fits;
-                    const uint32_t base = shard_reserve(ctl->n_items[level], tile, static_cast<uint32_t>(__popcll(lm)), F.item_cap, lane, fits);
+                    const uint32_t base = shard_reserve(ctl->n_items[level], &ctl->overflow, tile, static_cast<uint32_t>(__popcll(lm)), F.item_cap, lane, fits);
                     if (is_lit && fits) {
                         ShadeItem o;
                         o.ox = r.ox; o.oy = r.oy; o.oz = r.oz; o.dx = r.dx; o.dy = r.dy; o.dz = r.dz;
@@ -1490,7 +1493,7 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
         const unsigned long long sm = __ballot(spawn);
         if (sm != 0ull) {
             bool fits;
-            const uint32_t base = shard_reserve(ctl->n_rays[level + 1], tile, static_cast<uint32_t>(__popcll(sm)), F.ray_cap, lane, fits);
+            const uint32_t base = shard_reserve(ctl->n_rays[level + 1], &ctl->overflow, tile, static_cast<uint32_t>(__popcll(sm)), F.ray_cap, lane, fits);
             if (spawn && fits) { rays_out[base + lanes_below(sm)] = child; c_spawn += 1; }
         }
     }

@@ -426,6 +426,33 @@ def test_error_paths_on_device(rt, scenes):
     ctx.close()
     hs.close()
 @pytest.mark.gpu
+def test_leaf_task_queue_overflow_is_exact(rt, oracle, scenes):
+    """The leaf-task queue has a fixed capacity; pieces that do not fit are processed by the emitting wave.  With the
+    capacity forced down to a few hundred tasks (dodge emits ~170,000 per frame) most reservations straddle or miss the
+    end of the queue -- the frame must still be bit-identical to the one rendered with the default capacity."""
+    path = os.path.join(scenes, "dodgeColorTest.obj")
+    frames = []
+    for cap in (None, "64", "777", "20000"):
+        if cap is None:
+            os.environ.pop("RT_TASK_CAP", None)
+        else:
+            os.environ["RT_TASK_CAP"] = cap
+        fs = rt.Flyscene(scene_path=path)
+        fs.initialize(960, 540, True, False)
+        fs.usteps = fs.vsteps = 8
+        fs.max_depth = 2
+        rgb = fs.raytraceScene(960, 540, write_ppm=False, want_hits=True).copy()
+        frames.append((rgb, fs.hits.copy()))
+        again = fs.raytraceScene(960, 540, write_ppm=False).copy()         # and the same twice in a row
+        assert np.array_equal(rgb.view(np.uint32), again.view(np.uint32)), cap
+        fs.ctx.close()
+    os.environ.pop("RT_TASK_CAP", None)
+    for rgb, hits in frames[1:]:
+        assert np.array_equal(hits, frames[0][1])
+        assert np.array_equal(rgb.view(np.uint32), frames[0][0].view(np.uint32))
+
+
+@pytest.mark.gpu
 def test_plane_culling_is_exact_on_flat_scenes(rt, oracle, scenes):
     """cube.obj (one leaf: the FLAT kernels): per-unit plane culling of k_shadow, with the per-triangle constants prepared
     for the scene light and with per-unit boxes on the bounce levels (mirror cube: lmode items), against RT_NO_CULL=1 --
