@@ -352,7 +352,7 @@ def main():
         osc = orc.load_scene(scene_path)
         # the reference uses hardware_concurrency()-1 threads (flyscene.cpp:558); a 1-GPU box's CPU share is 16 cores
         threads = max(1, min(16, os.cpu_count() or 2) - 1)
-        stride = args.cpu_stride or 1
+        stride = args.cpu_stride or (8 if args.scene == "wavy" else 1)     # cfg4's whole 4K frame takes the oracle minutes: 1/64 of the pixels
         # whole frames of the same workload, repeated until ~10 s of CPU work (threads x wall) have been timed
         n = 0; sec = 0.0; cpu_rays = 0; reps = 0
         while reps == 0 or (sec * threads < 10.0 and reps < 64):
