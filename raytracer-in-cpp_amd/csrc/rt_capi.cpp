@@ -469,6 +469,8 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     std::memcpy(c->S.model, sc->model, sizeof(float) * 12);
     c->S.n_nodes = sc->n_nodes;
     c->S.n_faces = sc->n_faces;
+    c->S.queue_local = -1;        // auto (rt_kernels.hip, k_shadow); RT_QUEUE_LOCAL=n forces chunks of n consecutive units, 0 the strided mode
+    if (const char *ql = std::getenv("RT_QUEUE_LOCAL")) c->S.queue_local = std::atoi(ql);
     c->S.plane_cull = (no_cull || std::getenv("RT_NO_PLANE_CULL") != nullptr) ? 0 : 1;
     c->flat = (sc->nodes[0].count_flags & RT_NODE_LEAF) && (sc->nodes[0].count_flags & 0x7fffffffu) <= 64u;
     query_occupancy(c->flat, &c->occ_trace_primary, &c->occ_trace_rays, &c->occ_shadow, &c->occ_shade);

@@ -128,6 +128,7 @@ struct DScene {
     const rt_material *mats;
     float model[12];
     uint32_t n_nodes, n_faces;
+    int32_t queue_local;               // k_shadow queue: -1 auto, 0 strided chunks (balance first), n chunks of n consecutive units
     int32_t plane_cull;                // k_shadow: per-unit plane culling (rt_kernels.hip, SegPacket); RT_NO_PLANE_CULL=1 turns it off
 };
 

@@ -105,8 +105,11 @@ __device__ __forceinline__ bool box_hit_verified(const float *__restrict__ b, fl
 struct ShardedQueue {
     uint32_t *ctr;
     uint32_t total, chunk, nchunks, shard, tries, fetched, cur, cur_end;
+    uint32_t local;          // 0: strided chunks, interleaved heads (balance first); else: chunks of `local` CONSECUTIVE units and head x
+                             // owns the x-th eighth of the unit range (locality first: scenes that do not fit the 4 MB L2 of an XCD)
     int lane;
     __device__ __forceinline__ uint32_t chunks_of(uint32_t s) const {         // index range of head s (some ids may fall past nchunks)
+        if (local) { const uint32_t per = (nchunks + RT_QUEUE_SHARDS - 1u) / RT_QUEUE_SHARDS; return per; }
         const uint32_t groups = (nchunks + 31u) / 32u;
         return (groups / RT_QUEUE_SHARDS + ((groups % RT_QUEUE_SHARDS) > s ? 1u : 0u)) * 32u;
     }
@@ -118,14 +121,16 @@ struct ShardedQueue {
     // static variant (no atomics at all): wave w owns units w, w + W, w + 2W, ...  Best when units are cheap and
     // uniform (primary tiles: measured 0.25 ms static vs 0.39 ms dynamic on the cube frame).
     __device__ __forceinline__ void init_static(uint32_t total_units, uint32_t total_waves, uint32_t wave_id, int ln) {
+        local = 0u;
         ctr = nullptr; total = 0u; lane = ln; chunk = 1u; nchunks = total_waves; shard = 0; tries = 0; fetched = 0;
         cur = wave_id; cur_end = total_units;
     }
-    __device__ __forceinline__ void init(uint32_t *heads, uint32_t total_units, uint32_t total_waves, uint32_t home, int ln) {
-        ctr = heads; total = total_units; lane = ln;
+    __device__ __forceinline__ void init(uint32_t *heads, uint32_t total_units, uint32_t total_waves, uint32_t home, int ln, uint32_t local_chunk = 0u) {
+        ctr = heads; total = total_units; lane = ln; local = local_chunk;
         chunk = total_units / (total_waves * 6u);
         if (chunk < 1u) chunk = 1u;
-        nchunks = (total_units + chunk - 1u) / chunk;          // chunk c = { c + j * nchunks }
+        if (local) chunk = local;
+        nchunks = (total_units + chunk - 1u) / chunk;          // chunk c = { c + j * nchunks }   (local: { c * chunk + j })
         shard = home % RT_QUEUE_SHARDS; tries = 0; cur = 0; cur_end = 0;
         fetched = total ? grab() : 0u;
     }
@@ -133,7 +138,7 @@ struct ShardedQueue {
         // a chunk is NOT a run of consecutive units: chunk c owns units c, c + nchunks, c + 2*nchunks, ...  Expensive
         // units cluster (neighbouring hit points cross the same 979-triangle leaves); consecutive membership made
         // single chunks 5x heavier than average and doubled the kernel's tail.
-        if (cur < cur_end) { unit = cur; cur += nchunks; return true; }
+        if (cur < cur_end) { unit = cur; cur += local ? 1u : nchunks; return true; }
         if (total == 0u) return false;
         for (;;) {
             const uint32_t idx = uniform_u32(fetched);
@@ -142,9 +147,15 @@ struct ShardedQueue {
                 // group the waves of one XCD work on neighbouring hit points (same leaves -> that XCD's 4 MB L2) while the
                 // fine interleave keeps the heads equally loaded (fully contiguous ownership measured +17 % on dodge,
                 // chunk-granular interleave +5 % on the 1M-triangle scene)
-                const uint32_t c = ((idx / 32u) * RT_QUEUE_SHARDS + shard) * 32u + (idx % 32u);
+                const uint32_t c = local ? shard * chunks_of(shard) + idx : ((idx / 32u) * RT_QUEUE_SHARDS + shard) * 32u + (idx % 32u);
                 fetched = grab();                     // prefetch the following chunk index
                 if (c >= nchunks) { cur = 0; cur_end = 0; continue; }     // id past the end of the last partial group
+                if (local) {
+                    unit = c * chunk;
+                    cur = unit + 1u;
+                    cur_end = unit + chunk < total ? unit + chunk : total;
+                    return true;
+                }
                 unit = c;
                 cur = c + nchunks;
                 cur_end = total;
@@ -1197,7 +1208,11 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
         if (n_work > Q.cap) n_work = Q.cap;
         q.init_static(n_work, gridDim.x * RT_WAVES, uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave)), lane);
     } else {
-        q.init(ctl->queue[ctr_slot], static_cast<uint32_t>(units), gridDim.x * RT_WAVES, blockIdx.x, lane);
+        // N > 64: the passes of one (hit, light) pair are consecutive units and walk the same part of the tree -- hand them out two
+        // at a time (4K / 256 samples / 1 M triangles: k_shadow 40 -> 32 ms); otherwise balance first (neighbouring heavy units
+        // pile up: dodge 1.03 -> 1.9 ms with chunks of 8)
+        q.init(ctl->queue[ctr_slot], static_cast<uint32_t>(units), gridDim.x * RT_WAVES, blockIdx.x, lane,
+               S.queue_local >= 0 ? static_cast<uint32_t>(S.queue_local) : (P > 1u ? 2u : 0u));
     }
     for (uint32_t work = 0; q.next(work);) {
 #ifdef RT_PROFILE
