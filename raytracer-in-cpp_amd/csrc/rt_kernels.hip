@@ -793,11 +793,11 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const DNode *__restrict
                                                           const RayItem *__restrict__ rays_in, ShadeItem *__restrict__ items,
                                                           Control *__restrict__ ctl, float4 *__restrict__ rec,
                                                           int32_t *__restrict__ out_hit, float *__restrict__ out_t) {
-    __shared__ uint4 s_stage[RT_WAVES * RT_STAGE_TRIS * 5];
-    __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
-    __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
+    __shared__ uint4 s_stage[FLAT ? 1 : RT_WAVES * RT_STAGE_TRIS * 5];        // flat scenes need neither staging buffer nor stack
+    __shared__ unsigned long long s_mask[FLAT ? 1 : RT_WAVES * RT_STACK];
+    __shared__ uint32_t s_node[FLAT ? 1 : RT_WAVES * RT_STACK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, s_stage + wave * RT_STAGE_TRIS * 5};
+    const WaveStack stk{s_node + (FLAT ? 0 : wave * RT_STACK), s_mask + (FLAT ? 0 : wave * RT_STACK), s_stage + (FLAT ? 0 : wave * RT_STAGE_TRIS * 5)};
     ShardMap rmap{0u, 0u, 0u, 0u};
     if (!PRIMARY) rmap = shard_map(ctl->n_rays[level], lane, 0xffffffffu, 1u, 64u);
     const uint32_t ntiles = PRIMARY ? static_cast<uint32_t>(F.tiles_x) * static_cast<uint32_t>(F.tiles_y) : rmap.total;
@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
     __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
     __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, s_stage + wave * RT_STAGE_TRIS * 5};
+    const WaveStack stk{s_node + (false ? 0 : wave * RT_STACK), s_mask + (false ? 0 : wave * RT_STACK), s_stage + (false ? 0 : wave * RT_STAGE_TRIS * 5)};
     ShardMap rmap{0u, 0u, 0u, 0u};
     if (!PRIMARY) rmap = shard_map(ctl->n_rays[level], lane, 0xffffffffu, 1u, 64u);
     const uint32_t ntiles = PRIMARY ? static_cast<uint32_t>(F.tiles_x) * static_cast<uint32_t>(F.tiles_y) : rmap.total;
@@ -1159,11 +1159,11 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
                                                            const DScene S, const DLights L, const int level, const int ctr_slot,
                                                            const int lslots, const uint32_t item_cap, const ShadeItem *__restrict__ items,
                                                            Control *__restrict__ ctl, unsigned long long *vis, const TaskQueues Q) {
-    __shared__ uint4 s_stage[RT_WAVES * RT_STAGE_TRIS * 5];
-    __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
-    __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
+    __shared__ uint4 s_stage[FLAT ? 1 : RT_WAVES * RT_STAGE_TRIS * 5];        // flat scenes need neither staging buffer nor stack
+    __shared__ unsigned long long s_mask[FLAT ? 1 : RT_WAVES * RT_STACK];
+    __shared__ uint32_t s_node[FLAT ? 1 : RT_WAVES * RT_STACK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, s_stage + wave * RT_STAGE_TRIS * 5};
+    const WaveStack stk{s_node + (FLAT ? 0 : wave * RT_STACK), s_mask + (FLAT ? 0 : wave * RT_STACK), s_stage + (FLAT ? 0 : wave * RT_STAGE_TRIS * 5)};
     const uint32_t N = static_cast<uint32_t>(L.n_samples);
     const uint32_t G = N <= 64u ? 64u / N : 1u;              // (hit,light) pairs per wave
     const uint32_t P = (N + 63u) / 64u;                       // 64-sample passes (= mask words) per pair
@@ -1571,7 +1571,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_segments(const DNode *__restr
     __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
     __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, s_stage + wave * RT_STAGE_TRIS * 5};
+    const WaveStack stk{s_node + (false ? 0 : wave * RT_STACK), s_mask + (false ? 0 : wave * RT_STACK), s_stage + (false ? 0 : wave * RT_STAGE_TRIS * 5)};
     const DNode root = nodes[0];
     const int waves_total = gridDim.x * RT_WAVES;
     for (int base = (blockIdx.x * RT_WAVES + wave) * 64; base < n; base += waves_total * 64) {
