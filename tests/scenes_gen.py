@@ -4,6 +4,8 @@ mixed_materials: small OBJ+MTL that reaches the illum 3/4/5/6/7/9 branches of tr
 cube.obj (illum 4) and dodgeColorTest.obj (illum 2) never take.  No reference output exists for these scenes:
 the GPU path is compared with the CPU oracle only ("parity unpinned" branches).
 wavy_grid: the cfg4-style displaced grid z = 0.1 sin(9x) cos(7y) over an illum-4 floor.
+random_soup: seeded triangle soups for the fuzz parity test (clusters of small triangles, long slivers, zero-area and
+duplicate triangles, shared vertices, all material kinds) -- ill-conditioned input for the culling code.
 """
 import math
 import os
@@ -117,4 +119,74 @@ def wavy_grid(dirpath, n=64, name="wavy"):
     path = os.path.join(dirpath, name + ".obj")
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
+    return path
+
+
+def random_soup(dirpath, seed, n_tri, name=None):
+    """Seeded soup of n_tri triangles: 70 % small triangles in a few clusters, 2 % scene-sized and 6 % medium ones, 17 % slivers (aspect 1e3-1e6),
+    a few zero-area / repeated-vertex / duplicated triangles; 6 materials incl. mirror, Fresnel, glass and pass-through."""
+    import random
+    rnd = random.Random(seed)
+    name = name or f"soup_{seed}_{n_tri}"
+    mats = [("m_plain", 2, 12.0, 1.0), ("m_hi", 4, 40.0, 1.0), ("m_mirror", 3, 60.0, 1.45), ("m_fresnel", 5, 25.0, 1.5),
+            ("m_glass", 6, 90.0, 1.6), ("m_pass", 9, 10.0, 1.0)]
+    mtl = []
+    for mname, illum, ns, ni in mats:
+        kd = [round(rnd.uniform(0.1, 0.9), 3) for _ in range(3)]
+        ks = [round(rnd.uniform(0.1, 0.9), 3) for _ in range(3)]
+        mtl += [f"newmtl {mname}", f"Ns {ns}", "Kd %.3f %.3f %.3f" % tuple(kd), "Ks %.3f %.3f %.3f" % tuple(ks), f"Ni {ni}", f"illum {illum}"]
+    verts, faces = [], []
+    centres = [(rnd.uniform(-1, 1), rnd.uniform(-1, 1), rnd.uniform(-1, 1)) for _ in range(5)]
+
+    def vtx(p):
+        verts.append(p)
+        return len(verts)
+
+    for t in range(n_tri):
+        kind = rnd.random()
+        mat = rnd.choices(range(len(mats)), weights=[40, 25, 10, 8, 7, 10])[0]
+        if kind < 0.70:
+            c = rnd.choice(centres)
+            o = tuple(c[k] + rnd.gauss(0, 0.25) for k in range(3))
+            sz = rnd.uniform(0.02, 0.15)
+            tri = [tuple(o[k] + rnd.uniform(-sz, sz) for k in range(3)) for _ in range(3)]
+        elif kind < 0.72:
+            tri = [tuple(rnd.uniform(-1.5, 1.5) for _ in range(3)) for _ in range(3)]
+        elif kind < 0.78:                       # medium triangles
+            o = tuple(rnd.uniform(-1, 1) for _ in range(3))
+            tri = [tuple(o[k] + rnd.uniform(-0.4, 0.4) for k in range(3)) for _ in range(3)]
+        elif kind < 0.95:                       # sliver: two vertices far apart, the third almost on their line
+            a = tuple(rnd.uniform(-1.2, 1.2) for _ in range(3))
+            ln = rnd.uniform(0.05, 0.6)
+            b = tuple(a[k] + rnd.uniform(-ln, ln) for k in range(3))
+            w = rnd.random()
+            eps = 10.0 ** rnd.uniform(-6, -3)
+            c = tuple(a[k] + w * (b[k] - a[k]) + rnd.uniform(-eps, eps) for k in range(3))
+            tri = [a, b, c]
+        elif kind < 0.97:                       # zero area: all three on a line / two equal
+            a = tuple(rnd.uniform(-1, 1) for _ in range(3))
+            tri = [a, a, tuple(rnd.uniform(-1, 1) for _ in range(3))]
+        elif faces:                             # exact duplicate of an earlier triangle (t ties: lowest face id must win)
+            faces.append((mat, faces[rnd.randrange(len(faces))][1]))
+            continue
+        else:
+            tri = [tuple(rnd.uniform(-1, 1) for _ in range(3)) for _ in range(3)]
+        if faces and rnd.random() < 0.3:        # share a vertex with the previous triangle
+            ids = (faces[-1][1][rnd.randrange(3)], vtx(tri[1]), vtx(tri[2]))
+        else:
+            ids = (vtx(tri[0]), vtx(tri[1]), vtx(tri[2]))
+        faces.append((mat, ids))
+    obj = [f"mtllib {name}.mtl"] + ["v %.7f %.7f %.7f" % p for p in verts]
+    cur = None
+    for mat, (a, b, c) in faces:
+        if mat != cur:
+            obj.append(f"usemtl {mats[mat][0]}")
+            cur = mat
+        obj.append(f"f {a} {b} {c}")
+    os.makedirs(dirpath, exist_ok=True)
+    with open(os.path.join(dirpath, name + ".mtl"), "w") as f:
+        f.write("\n".join(mtl) + "\n")
+    path = os.path.join(dirpath, name + ".obj")
+    with open(path, "w") as f:
+        f.write("\n".join(obj) + "\n")
     return path
