@@ -83,6 +83,34 @@ def test_small_capacity_tree_matches_oracle(rt, oracle, scenes):
     osc.close()
 
 
+@pytest.mark.parametrize("seed,n_tri,cap", [(7, 3000, 1000), (8, 800, 250), (10, 1500, 250), (12, 40, 1000), (17, 1200, 300), (21, 700, 200)])
+def test_random_soup_scene_matches_oracle(rt, oracle, tmp_path, seed, n_tri, cap):
+    """Seeded triangle soups (slivers, zero-area and duplicated triangles, shared vertices, six materials): loader,
+    normalisation, normals and the bug-compatible octree of the product are bit-identical to the oracle's."""
+    import scenes_gen
+    path = scenes_gen.random_soup(str(tmp_path), seed, n_tri)
+    hs = rt.HostScene(path, leaf_capacity=cap, max_depth=15)
+    osc = oracle.load_scene(path, capacity=cap, maxdepth=15)
+    a, o = hs.arrays(), osc.arrays()
+    assert np.array_equal(a["tri_vid"], o["face_vid"]) and np.array_equal(a["mat_id"], o["face_mat"])
+    assert np.array_equal(a["face_normal"].view(np.uint32), o["face_normal"].view(np.uint32))      # NaN normals of zero-area faces included
+    assert np.array_equal(a["vert_normal"].view(np.uint32), o["normals"].view(np.uint32))
+    world = o["wverts"][o["face_vid"].astype(np.int64)].reshape(-1, 9)
+    assert np.array_equal(a["tri_verts"].view(np.uint32), world.view(np.uint32))
+    want = flat_tree_from_oracle(osc)
+    assert len(want) == a["node_box"].shape[0]
+    for i, (kind, box, payload) in enumerate(want):
+        assert np.array_equal(a["node_box"][i].view(np.uint32), box.view(np.uint32)), i
+        cf = int(a["node_count_flags"][i])
+        if kind == "leaf":
+            first, cnt = int(a["node_first"][i]), cf & 0x7FFFFFFF
+            assert cf & RT_NODE_LEAF and np.array_equal(a["face_refs"][first:first + cnt].astype(np.int32), payload)
+        else:
+            assert not (cf & RT_NODE_LEAF) and (cf & 0x7FFFFFFF) == payload
+    hs.close()
+    osc.close()
+
+
 def test_camera_and_lights_match_oracle(rt, oracle):
     import ctypes as C
     lib = rt.load_library()
