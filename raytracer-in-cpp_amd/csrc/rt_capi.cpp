@@ -280,44 +280,18 @@ static void build_chunk_bounds(const rt_scene *sc, std::vector<uint32_t> &refs, 
                 bary_infl = std::max(bary_infl, 5e-6 * (d00 * d11 / den) * edge);
             }
             if (ok) {
-                // optional fast path: normal cone of the chunk (sign-aligned normals).  A ray with
-                // |cos(d, axis)| > sin(cone + guard) is farther than the guard angle from EVERY plane of the chunk, so
-                // the per-triangle guard of the kernel can be skipped for it.
-                double axis[3] = {0, 0, 0}, first_n[3] = {0, 0, 0};
-                for (uint32_t i = 0; i < n; ++i) {
-                    const float *nn = sc->face_normal + static_cast<size_t>(r[c0 + i]) * 3;
-                    double sgn = 1.0;
-                    if (i == 0) { for (int k = 0; k < 3; ++k) first_n[k] = nn[k]; }
-                    else if (first_n[0] * nn[0] + first_n[1] * nn[1] + first_n[2] * nn[2] < 0) sgn = -1.0;
-                    for (int k = 0; k < 3; ++k) axis[k] += sgn * nn[k];
-                }
-                const double al = std::sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
-                cb.pad0 = 2.0f;                                   // no cone
-                if (al > 1e-6) {
-                    for (int k = 0; k < 3; ++k) axis[k] /= al;
-                    double min_cos = 1.0;
-                    for (uint32_t i = 0; i < n; ++i) {
-                        const float *nn = sc->face_normal + static_cast<size_t>(r[c0 + i]) * 3;
-                        min_cos = std::min(min_cos, std::fabs(axis[0] * nn[0] + axis[1] * nn[1] + axis[2] * nn[2]));   // unit normals (checked above)
-                    }
-                    const double cone = std::acos(std::min(1.0, min_cos)) + std::asin(0.002) + 2e-3;   // + guard angle + float slack
-                    if (cone < 1.45) {
-                        cb.ax = static_cast<float>(axis[0]); cb.ay = static_cast<float>(axis[1]); cb.az = static_cast<float>(axis[2]);
-                        cb.pad0 = std::nextafter(static_cast<float>(std::sin(cone)), 2.0f);
-                    }
-                }
                 const double infl = bary_infl + 1e-3 * max_edge + 1e-4 * extent;
                 for (int k = 0; k < 3; ++k) {
                     cb.lo[k] = std::nextafter(static_cast<float>(lo[k] - infl), -INFINITY);
                     cb.hi[k] = std::nextafter(static_cast<float>(hi[k] + infl), INFINITY);
                 }
-                cb.sin_guard = 0.0f;
+                cb.never = 0.0f;
             }
-            if (!ok) { cb = ChunkBound{}; cb.sin_guard = 2.0f; cb.pad0 = 2.0f; }
+            if (!ok) { cb = ChunkBound{}; cb.never = 2.0f; }
             out.push_back(cb);
         }
     }
-    if (out.empty()) { ChunkBound cb{}; cb.sin_guard = 2.0f; cb.pad0 = 2.0f; out.push_back(cb); }
+    if (out.empty()) { ChunkBound cb{}; cb.never = 2.0f; out.push_back(cb); }
 }
 
 // host-only: builds the chunk bounds of a flattened scene and reports {chunks, cullable chunks, leaves, max chunks per leaf}
@@ -330,7 +304,7 @@ extern "C" rt_status rt_debug_chunk_stats(const rt_scene *sc, int32_t out[4]) {
     for (size_t i = 0; i < static_cast<size_t>(sc->n_faces) * 9; ++i) extent = std::fmax(extent, std::fabs(sc->tri_verts[i]));
     build_chunk_bounds(sc, refs, leaf_chunk0, cbs, extent, false);
     int cullable = 0, leaves = 0, maxc = 0;
-    for (const ChunkBound &cb : cbs) cullable += cb.sin_guard < 1.5f ? 1 : 0;
+    for (const ChunkBound &cb : cbs) cullable += cb.never < 1.5f ? 1 : 0;
     for (uint32_t i = 0; i < sc->n_nodes; ++i)
         if (sc->nodes[i].count_flags & RT_NODE_LEAF) {
             ++leaves;
@@ -428,7 +402,7 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
         if (n.count_flags & RT_NODE_LEAF) {
             for (uint32_t k = 0; k < (cnt + 63u) / 64u; ++k) {
                 const ChunkBound &cb = cbs[leaf_chunk0[ii] + k];
-                if (cb.sin_guard >= 1.5f) open_box = true; else grow(cb.lo, cb.hi);
+                if (cb.never >= 1.5f) open_box = true; else grow(cb.lo, cb.hi);
             }
         } else {
             for (uint32_t k = 0; k < cnt; ++k) {
@@ -662,8 +636,8 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
     out->pixels = F.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;
 #ifdef RT_PROFILE
     if (!counted) {
-        std::fprintf(stderr, "RT_PROFILE ray-mode steps %llu useful %llu | tri-mode steps %llu useful %llu | box steps %llu useful %llu | leaves ray %llu tri %llu live-at-tri %llu | cone-culled pairs %llu guard-culled %llu guard-kept %llu\n",
-                     h.prof[0], h.prof[1], h.prof[2], h.prof[3], h.prof[4], h.prof[5], h.prof[6], h.prof[7], h.prof[8], h.prof[14], h.prof[12], h.prof[13]);
+        std::fprintf(stderr, "RT_PROFILE ray-mode steps %llu useful %llu | tri-mode steps %llu useful %llu | box steps %llu useful %llu | leaves ray %llu tri %llu live-at-tri %llu | chunk-culled (ray,chunk) pairs %llu\n",
+                     h.prof[0], h.prof[1], h.prof[2], h.prof[3], h.prof[4], h.prof[5], h.prof[6], h.prof[7], h.prof[8], h.prof[14]);
         std::fprintf(stderr, "RT_PROFILE plane cull: ray-mode triangles skipped %llu, tri-mode chunks skipped %llu; content-box culled (ray,node) pairs %llu\n", h.prof[64], h.prof[65], h.prof[66]);
         std::fprintf(stderr, "RT_PROFILE shadow units %llu: cycles max %llu mean %.0f; log2 histogram:", h.prof[11], h.prof[9], h.prof[11] ? double(h.prof[10]) / double(h.prof[11]) : 0.0);
         for (int b = 8; b <= 30; ++b) std::fprintf(stderr, " [2^%d]=%llu", b, h.prof[16 + b]);

@@ -35,19 +35,15 @@ struct alignas(16) TriRec {
 };
 static_assert(sizeof(TriRec) == 80, "TriRec must be 80 bytes");
 
-// Conservative bound of one 64-triangle chunk of a leaf (lanes = triangles mode).  A ray may skip the chunk only when
-// it is provably impossible for ANY triangle of the chunk to pass rayTriangleIntersection AS THE REFERENCE COMPUTES
-// IT IN FLOAT (see rt_capi.cpp: build_chunk_bounds for the error analysis): the ray line misses the inflated AABB
-// AND the ray is not within the guard angle of being parallel to any triangle plane of the chunk (checked per triangle
-// in the kernel: |d.n| > tau |d|).
+// Conservative bound of one 64-triangle chunk of a leaf.  A ray may skip the chunk only when it is provably impossible for ANY
+// triangle of the chunk to pass rayTriangleIntersection AS THE REFERENCE COMPUTES IT IN FLOAT with a t the caller still counts:
+// the point of an accepted hit lies inside this inflated box (rt_capi.cpp: build_chunk_bounds has the error analysis).
 struct alignas(16) ChunkBound {
     float lo[3], hi[3];      // AABB of the chunk's triangles, inflated
-    float ax, ay, az;        // normal-cone axis (valid when pad0 < 1.5)
-    float sin_guard;         // 0: chunk may be culled; 2: never (ill-conditioned / degenerate / non-finite triangle inside)
-    float pad0;              // sin(cone half-angle + guard angle), or 2 when the chunk has no usable cone
-    float pad1;
+    float never;             // 0: the chunk may be culled; 2: never (ill-conditioned / degenerate / non-finite triangle inside)
+    float pad;
 };
-static_assert(sizeof(ChunkBound) == 48, "ChunkBound must be 48 bytes");
+static_assert(sizeof(ChunkBound) == 32, "ChunkBound must be 32 bytes");
 
 struct alignas(16) RayItem {     // a bounce ray (level >= 1) or an rt_trace_rays input ray
     float ox, oy, oz, dx;

@@ -443,7 +443,7 @@ __device__ __forceinline__ void packet_walk(const DNode *__restrict__ nodes, con
                     unsigned long long todo = live;
                     {
                         const ChunkBound bd = cbounds[c0 >> 6];
-                        if (bd.sin_guard < 1.5f) {
+                        if (bd.never < 1.5f) {
                             const float t0x = (bd.lo[0] - slab_pad - ox) * idx_, t1x = (bd.hi[0] + slab_pad - ox) * idx_;
                             const float t0y = (bd.lo[1] - slab_pad - oy) * idy_, t1y = (bd.hi[1] + slab_pad - oy) * idy_;
                             const float t0z = (bd.lo[2] - slab_pad - oz) * idz_, t1z = (bd.hi[2] + slab_pad - oz) * idz_;
