@@ -749,6 +749,14 @@ __device__ __forceinline__ uint32_t shard_reserve(uint32_t *counters, uint32_t *
 }
 
 // arealight::getPointLights / createSpherePoint (arealight.hpp:15-25, flyscene.cpp:956-972): sample s of light p
+// N > 64 samples: a k_shadow pass holds 64 of them.  When both grid sides are multiples of 8 a pass is an 8x8 BLOCK of the grid
+// (pass p = block (p / (vsteps/8), p % (vsteps/8)), lane l = cell (l / 8, l % 8) of it) instead of 64 consecutive samples (a
+// 4 x 16 strip of a 16 x 16 light): the 64 segments of a unit form a tighter bundle (-6 % on cfg4's k_shadow).  The visibility
+// word of pass p keeps bit l for lane l, so k_shade looks sample (i, j) up in word (i/8)*(vsteps/8) + j/8, bit (i%8)*8 + j%8.
+__device__ __forceinline__ bool sample_blocks(const DLights &L) {
+    return L.n_samples > 64 && (L.usteps & 7) == 0 && (L.vsteps & 7) == 0;
+}
+
 // The sample grid of one light: sample (i, j) = ((i + 0.5) * cx, (j + 0.5) * cy, z).  cx and cy each hold a float division, so a
 // caller that needs several samples of the same light (k_shadow: the lane's sample + the two corners of the sample box) builds
 // the grid once; (i, j) = (s / vsteps, s % vsteps) are passed as the floats i + 0.5 and j + 0.5, which the callers keep out of
@@ -1179,6 +1187,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     const uint32_t vst = static_cast<uint32_t>(L.vsteps > 0 ? L.vsteps : 1);
     const float fi_lane = static_cast<float>(s_in / vst) + 0.5f, fj_lane = static_cast<float>(s_in % vst) + 0.5f;
     const float fi_last = static_cast<float>(L.usteps - 1) + 0.5f, fj_last = static_cast<float>(L.vsteps - 1) + 0.5f;
+    const bool blocks = sample_blocks(L);
 
     LanePlane plane{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (FLAT && static_cast<uint32_t>(lane) < (root.count_flags & 0x7fffffffu)) {
@@ -1246,6 +1255,10 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
             slot_ok = valid;
         } else {
             g = lu / P; pass = lu - g * P; s = pass * 64u + s_in;
+            if (blocks) {
+                const uint32_t bpr = vst >> 3, bi = pass / bpr, bj = pass - bi * bpr;
+                s = (bi * 8u + (s_in >> 3)) * vst + bj * 8u + (s_in & 7u);
+            }
             valid = s < N;
         }
         const uint32_t item_i = valid ? (lslots == 1 ? g : g / static_cast<uint32_t>(lslots)) : 0u;
@@ -1447,10 +1460,18 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
                 const LightGrid lg = light_grid(L, px, py, pz);
                 uint32_t si = 0, sj = 0;                       // s = si * vsteps + sj, kept as counters: no division per sample
                 const uint32_t vst = static_cast<uint32_t>(L.vsteps > 0 ? L.vsteps : 1);
+                const bool blocks = sample_blocks(L);
+                const uint32_t bpr = vst >> 3;
 #pragma unroll 2
                 for (uint32_t s = 0; s < N; ++s) {
-                    if ((s & 63u) == 0u) word = vw[s >> 6];
-                    const bool visible = ((word >> (s & 63u)) & 1ull) != 0ull;
+                    uint32_t bit = s & 63u;
+                    if (blocks) {
+                        if ((sj & 7u) == 0u) word = vw[(si >> 3) * bpr + (sj >> 3)];       // a new block every 8 samples of a grid row
+                        bit = ((si & 7u) << 3) | (sj & 7u);
+                    } else if (bit == 0u) {
+                        word = vw[s >> 6];
+                    }
+                    const bool visible = ((word >> bit) & 1ull) != 0ull;
                     sum += visible ? 1.0f : 0.0f;
                     float sx, sy, sz;
                     grid_sample(lg, static_cast<float>(si) + 0.5f, static_cast<float>(sj) + 0.5f, sx, sy, sz);
