@@ -70,6 +70,8 @@ struct rt_ctx {
     uint32_t task_cap = 1u << 21;
     uint32_t trace_budget = 1000u;              // leaves above this estimated cost (VALU instructions) become tasks (0 = off)
     uint32_t shadow_budget = 1500u;
+    int stage_mult = 2;                         // grid multiplier of the main k_stage launches (RT_STAGE_MULT): twice the resident grid lets
+                                                // blocks of sky tiles retire early and evens out the object tiles (dodge trace 0.278 -> 0.254 ms)
     uint32_t task_target = 0u;                  // estimated cost of one leaf-task piece (0 = same as the budget)
     float4 *d_rec = nullptr;
     float *d_fres = nullptr;
@@ -123,6 +125,7 @@ extern "C" rt_status rt_create(rt_ctx **out, int device) {
     if (const char *dt = std::getenv("RT_TRACE_DYNAMIC")) c->dyn_trace = std::atoi(dt) != 0;
     if (const char *sb = std::getenv("RT_SHADOW_BUDGET")) c->shadow_budget = static_cast<uint32_t>(std::atoi(sb));
     if (const char *sg = std::getenv("RT_STAGED_TRACE")) c->staged_trace = std::atoi(sg) != 0;
+    if (const char *sm = std::getenv("RT_STAGE_MULT")) { const int v = std::atoi(sm); if (v >= 1 && v <= 8) c->stage_mult = v; }
     if (const char *tc = std::getenv("RT_TASK_CAP")) { const long v = std::atol(tc); if (v >= 64 && v <= (1l << 24)) c->task_cap = static_cast<uint32_t>(v); }
     if (const char *tt = std::getenv("RT_TASK_TARGET")) c->task_target = static_cast<uint32_t>(std::atoi(tt));
     if (const char *tb = std::getenv("RT_TRACE_BUDGET")) c->trace_budget = static_cast<uint32_t>(std::atoi(tb));
@@ -568,7 +571,7 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
             const uint32_t B = count ? 0u : c->trace_budget, cap = c->task_cap;
             for (int stage = 0; stage < 2; ++stage) {
                 const uint32_t q0 = static_cast<uint32_t>(stage);
-                launch_stage(prim, count, stage, false, tgrid, st, c->S, c->d_cam, L, F, level, lslots, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
+                launch_stage(prim, count, stage, false, tgrid * c->stage_mult, st, c->S, c->d_cam, L, F, level, lslots, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
                              hit_l, t_l, c->d_best, c->d_lit, TaskQueues{nullptr, B ? c->d_tasks[stage] : nullptr, 0u, q0, cap, B, c->task_target});
                 if (B != 0u)
                     launch_stage(prim, false, stage, true, tgrid, st, c->S, c->d_cam, L, F, level, lslots, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
