@@ -211,8 +211,8 @@ def test_row_shards_stitch_to_the_full_frame(dodge, rt):
 
 
 def test_full_size_cfg2_properties(cube, dodge, oracle):
-    """BASELINE cfg2 at full size (1920x1080, depth 4, 8x8 = 64 samples): determinism, shard-stitch identity, and
-    oracle parity on a band of rows (the oracle takes seconds for a band, not the whole frame)."""
+    """BASELINE cfg2 at full size (1920x1080, depth 4, 8x8 = 64 samples): determinism and oracle parity on the WHOLE frame
+    (2,073,600 pixels: every closest-hit face id exact, RGB within 1e-5, 8-bit values equal)."""
     import ctypes as C
     w, h = 1920, 1080
     for pair in (cube, dodge):
@@ -225,7 +225,7 @@ def test_full_size_cfg2_properties(cube, dodge, oracle):
         b = fs.raytraceScene(w, h, write_ppm=False, want_hits=True)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "two renders of the same frame must be bit-identical"
         assert hashlib.sha256(a.tobytes()).hexdigest() == hashlib.sha256(b.tobytes()).hexdigest()
-        band = (500, 540)
+        band = (0, h)                          # the whole frame: the oracle needs ~1 s for it on the box's host cores
         ref, rhits, _ = pair.osc.render(oracle.camera(w, h), oracle.lights(area=True, usteps=8, vsteps=8), w, h, max_depth=4,
                                         threads=8, row0=band[0], row1=band[1], want_hits=True)
         assert_frame_parity(oracle, a[band[0]:band[1]], fs.hits[band[0]:band[1]], ref, rhits)
