@@ -28,8 +28,8 @@ BOX_BYTES, TRI_REF_BYTES = 24, 52   # algorithmic bytes per bo
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scene", default="cube", choices=["cube", "dodge", "wavy"],
                     help="wavy = the ~1M-triangle synthetic mesh of BASELINE cfg4 (use with --width 3840 --height 2160 --grid 16 --depth 8)")
     ap.add_argument("--width", type=int, default=1920)
