@@ -645,6 +645,15 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
         std::fprintf(stderr, "RT_PROFILE shadow units %llu: cycles max %llu mean %.0f; log2 histogram:", h.prof[11], h.prof[9], h.prof[11] ? double(h.prof[10]) / double(h.prof[11]) : 0.0);
         for (int b = 8; b <= 30; ++b) std::fprintf(stderr, " [2^%d]=%llu", b, h.prof[16 + b]);
         std::fprintf(stderr, "\n");
+        {
+            static const char *nm[8] = {"walk-other", "pop+node-load", "inner-children", "leaf-tri-mode", "leaf-scalar", "leaf-staged", "unit-setup(+queue)", "unit-finish"};
+            for (int k = 0; k < 2; ++k) {
+                unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += h.prof[72 + 8 * k + i];
+                std::fprintf(stderr, "RT_PROFILE k_shadow%s wave-cycles by phase (total %llu):", k ? "<CONT>" : "", tot);
+                for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s=%.1f%%", nm[i], tot ? 100.0 * double(h.prof[72 + 8 * k + i]) / double(tot) : 0.0);
+                std::fprintf(stderr, "\n");
+            }
+        }
         std::fprintf(stderr, "RT_PROFILE slowest trace tile %llu: ray-mode leaf triangles %llu, tri-mode leaf triangles %llu, tri-mode (ray,chunk) tests %llu, child boxes %llu\n",
                      h.prof[56], h.prof[57], h.prof[58], h.prof[59], h.prof[60]);
         std::fprintf(stderr, "RT_PROFILE trace tiles: cycles max %llu sum %llu; log2 histogram:", h.prof[38], h.prof[39]);

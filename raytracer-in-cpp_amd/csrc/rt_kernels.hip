@@ -277,6 +277,9 @@ __device__ __forceinline__ bool plane_rules_out_prepared(const SegPacket &g, con
 }
 
 // How a packet walk starts and when it gives work away.
+#ifdef RT_PROFILE
+struct PhaseClock;
+#endif
 struct WalkCtl {
     bool resume;                      // leaf task: process chunks [c_begin, c_end) of leaf `start_node` for `start_mask`, nothing else
     uint32_t start_node;
@@ -289,8 +292,15 @@ struct WalkCtl {
     uint32_t target;                  // estimated cost of one task piece
     uint32_t task_cap;
     SegPacket seg;                    // shadow units: plane culling (off for every other kind of packet)
+#ifdef RT_PROFILE
+    PhaseClock *pc;
+#endif
 };
+#ifdef RT_PROFILE
+__device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, 0u, 0u, nullptr, nullptr, 1u, 0u, seg_off(), nullptr}; }
+#else
 __device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, 0u, 0u, nullptr, nullptr, 1u, 0u, seg_off()}; }
+#endif
 
 __device__ __forceinline__ TriRec tri_from_regs(const u32x16 &lo, const u32x4 &hi) {
     TriRec t;
@@ -339,6 +349,19 @@ __device__ unsigned long long *g_prof = nullptr;
 #else
 #define RT_PROF_ADD(lane, idx, val) do { } while (0)
 #endif
+#ifdef RT_PROFILE
+// per-wave phase clock (diagnostic build): cycles spent in each phase of a unit, accumulated in registers and flushed with one
+// atomic per phase at kernel end -> prof[70 + phase] (undistorted by per-step atomics; build WITHOUT RT_PROFILE_STEPS)
+struct PhaseClock {
+    long long last; int cur; long long acc[8];
+    __device__ __forceinline__ void start() { last = clock64(); cur = 0; for (int i = 0; i < 8; ++i) acc[i] = 0; }
+    __device__ __forceinline__ void to(int p) { const long long t = clock64(); acc[cur] += t - last; last = t; cur = p; }
+    __device__ __forceinline__ void flush(int lane, int base) { to(0); if (lane == 0 && g_prof) for (int i = 0; i < 8; ++i) atomicAdd(&g_prof[base + i], static_cast<unsigned long long>(acc[i])); }
+};
+#define RT_PH(wc, p) do { if ((wc).pc) (wc).pc->to(p); } while (0)
+#else
+#define RT_PH(wc, p) do { } while (0)
+#endif
 // prof[0] ray-mode triangle steps   prof[1] ray-mode useful lane tests
 // prof[2] tri-mode (ray,chunk) steps prof[3] tri-mode useful lane tests
 // prof[4] box-test steps            prof[5] box-test useful lanes
@@ -376,6 +399,7 @@ __device__ __forceinline__ void packet_walk(const DNode *__restrict__ nodes, con
     }
     while (sp > 0) {
         --sp;
+        RT_PH(wc, 1);
         __builtin_amdgcn_wave_barrier();
         const uint32_t ni = uniform_u32(stk.node[sp]);
         const unsigned long long m = uniform_u64(stk.mask[sp]);
@@ -421,6 +445,7 @@ __device__ __forceinline__ void packet_walk(const DNode *__restrict__ nodes, con
             }
             RT_PROF_ADD(lane, tri_mode ? 7 : 6, 1);
             RT_TILE_COUNT(stk, lane, tri_mode ? 1 : 0, cnt);
+            RT_PH(wc, tri_mode ? 3 : (cnt <= RT_SCALAR_LEAF_MAX ? 4 : 5));
             if (tri_mode) {
                 RT_PROF_ADD(lane, 8, __popcll(live));
                 // ---- lanes = triangles.  Each lane keeps ONE leaf triangle in registers (coalesced 80-B records, next
@@ -582,6 +607,7 @@ __device__ __forceinline__ void packet_walk(const DNode *__restrict__ nodes, con
             }
         } else {
             RT_TILE_COUNT(stk, lane, 3, cnt);
+            RT_PH(wc, 2);
             for (uint32_t c = 0; c < cnt; ++c) {
                 const uint32_t ci = nd.first + c;
                 const DNode ch = nodes[ci];
@@ -612,6 +638,7 @@ __device__ __forceinline__ void packet_walk(const DNode *__restrict__ nodes, con
             }
         }
     }
+    RT_PH(wc, 0);
 }
 
 // Flat scenes (the root is itself a small leaf -- cube.obj: 1 node, 12 triangles): no stack, no LDS, no mode choice;
@@ -819,7 +846,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const DNode *__restrict
     if (F.dyn_trace) q.init(ctl->queue[ctr_slot], ntiles, gridDim.x * RT_WAVES, blockIdx.x, lane);
     else q.init_static(ntiles, gridDim.x * RT_WAVES, uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave)), lane);
     for (uint32_t tile = 0; q.next(tile);) {
-#ifdef RT_PROFILE
+#ifdef RT_PROFILE_HIST
         const long long prof_t0 = clock64();
         if (lane == 0) { stk.node[RT_STACK - 4] = 0; stk.node[RT_STACK - 3] = 0; stk.node[RT_STACK - 2] = 0; stk.node[RT_STACK - 1] = 0; }
 #endif
@@ -912,7 +939,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const DNode *__restrict
                 items[base + lanes_below(lm)] = o;
             }
         }
-#ifdef RT_PROFILE
+#ifdef RT_PROFILE_HIST
         {   // per-tile cycle histogram of k_trace: prof[40 + log2(cycles)] (capped at 2^23), max prof[38], sum prof[39]
             const unsigned long long dt = static_cast<unsigned long long>(clock64() - prof_t0);
             if (lane == 0 && g_prof) {
@@ -1223,12 +1250,21 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
         q.init(ctl->queue[ctr_slot], static_cast<uint32_t>(units), gridDim.x * RT_WAVES, blockIdx.x, lane,
                S.queue_local >= 0 ? static_cast<uint32_t>(S.queue_local) : (P > 1u ? 2u : 0u));
     }
+#ifdef RT_PROFILE
+    PhaseClock pclk; pclk.start();
+#endif
     for (uint32_t work = 0; q.next(work);) {
 #ifdef RT_PROFILE
+        pclk.to(6);
+#endif
+#ifdef RT_PROFILE_HIST
         const long long prof_t0 = clock64();
 #endif
         uint32_t unit = work;
         WalkCtl wc = walk_plain();
+#ifdef RT_PROFILE
+        wc.pc = &pclk;
+#endif
         if (CONT) {
             const ContTask task = Q.tasks_in[work];
             unit = uniform_u32(task.unit);
@@ -1308,7 +1344,13 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
         }
         float t_unused = 0.f; int f_unused = -1;
         bool occ = false;
+#ifdef RT_PROFILE
+        pclk.to(0);
+#endif
         walk<true, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, wc, plane, sroot, sx, sy, sz, ddx, ddy, ddz, ddx, ddy, ddz, srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref);
+#ifdef RT_PROFILE
+        pclk.to(7);
+#endif
         if (CONT) {
             const unsigned long long om = __ballot(valid && occ);
             if (N <= 64u) {
@@ -1325,7 +1367,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
                 vis[vis_index] = vm;
             }
         }
-#ifdef RT_PROFILE
+#ifdef RT_PROFILE_HIST
         {   // per-unit cycle histogram: prof[16 + log2(cycles)], max in prof[9], sum in prof[10], count in prof[11]
             const unsigned long long dt = static_cast<unsigned long long>(clock64() - prof_t0);
             if (lane == 0 && g_prof) {
@@ -1336,6 +1378,9 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
         }
 #endif
     }
+#ifdef RT_PROFILE
+    pclk.flush(lane, CONT ? 80 : 72);
+#endif
     c_rays = wave_sum(c_rays);
     if (COUNT) { c_box = wave_sum(c_box); c_ref = wave_sum(c_ref); }
     if (lane == 0) {
