@@ -20,6 +20,8 @@ void launch_trace(bool primary, bool count, bool flat, int grid, hipStream_t st,
                   int level, int slot, const RayItem *rays_in, ShadeItem *items, Control *ctl, float4 *rec, int32_t *out_hit, float *out_t);
 void launch_shadow(bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
                    uint32_t item_cap, const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target);
+void launch_shadow_shaft(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots, uint32_t item_cap,
+                         const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target);
 void launch_shadow_cont(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, uint32_t item_cap, const ShadeItem *items,
                         Control *ctl, unsigned long long *vis, const ContTask *tasks_in, ContTask *tasks_out, uint32_t q_in, uint32_t q_out,
                         uint32_t cap, uint32_t budget);
@@ -69,7 +71,7 @@ struct rt_ctx {
     ContTask *d_tasks[2] = {nullptr, nullptr};   // continuation queues of k_shadow (tree scenes)
     uint32_t task_cap = 1u << 21;
     uint32_t trace_budget = 1000u;              // leaves above this estimated cost (VALU instructions) become tasks (0 = off)
-    uint32_t shadow_budget = 1500u;
+    uint32_t shadow_budget = 3000u;
     int stage_mult = 2;                         // grid multiplier of the main k_stage launches (RT_STAGE_MULT): twice the resident grid lets
                                                 // blocks of sky tiles retire early and evens out the object tiles (dodge trace 0.278 -> 0.254 ms)
     uint32_t task_target = 0u;                  // estimated cost of one leaf-task piece (0 = same as the budget)
@@ -410,17 +412,23 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
         } else {
             for (uint32_t k = 0; k < cnt; ++k) {
                 const DNode &ch = dnodes[n.first + k];
-                if (ch.clo[0] <= -3e38f) open_box = true;
-                else if (!(ch.clo[0] >= 1e30f)) grow(ch.clo, ch.chi);
+                if (ch.pad[1]) open_box = true;
+                if (!(ch.clo[0] >= 1e30f)) grow(ch.clo, ch.chi);
             }
         }
+        // The content box bounds the CULLABLE chunks below; pad[1] = 1 marks a subtree that also holds a chunk that may never be skipped
+        // (a degenerate / ill-conditioned triangle inside): the walk then descends on the reference's own box test alone and the leaf's
+        // cullable chunks are still skipped one by one.  (Opening the whole content box instead let 15 sliver triangles of
+        // dodgeColorTest.obj -- 23 of its 437 chunks -- switch the content culling off for most of the top of the tree.)
+        bool finite = true;
+        for (int k = 0; k < 3; ++k) finite = finite && std::isfinite(lo[k]) && std::isfinite(hi[k]);
+        if (!finite) open_box = true;
         for (int k = 0; k < 3; ++k) {
-            const bool finite = std::isfinite(lo[k]) && std::isfinite(hi[k]);
-            dn.clo[k] = (open_box || !finite) ? -3e38f : lo[k];
-            dn.chi[k] = (open_box || !finite) ? 3e38f : hi[k];
+            dn.clo[k] = finite ? lo[k] : 1e30f;
+            dn.chi[k] = finite ? hi[k] : 1e30f;
         }
-        if (open_box) { dn.clo[0] = dn.clo[1] = dn.clo[2] = -3e38f; dn.chi[0] = dn.chi[1] = dn.chi[2] = 3e38f; }
-        dn.pad[0] = dn.pad[1] = 0u;
+        dn.pad[0] = (n.count_flags & RT_NODE_LEAF) ? leaf_chunk0[ii] : 0u;
+        dn.pad[1] = open_box ? 1u : 0u;
     }
     if ((st = upload(c, &c->d_nodes, dnodes.data(), dnodes.size())) != RT_OK) return st;
     if ((st = upload(c, &c->d_tris, recs.data(), recs.size())) != RT_OK) return st;
@@ -449,6 +457,10 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     c->S.queue_local = -1;        // auto (rt_kernels.hip, k_shadow); RT_QUEUE_LOCAL=n forces chunks of n consecutive units, 0 the strided mode
     if (const char *ql = std::getenv("RT_QUEUE_LOCAL")) c->S.queue_local = std::atoi(ql);
     c->S.plane_cull = (no_cull || std::getenv("RT_NO_PLANE_CULL") != nullptr) ? 0 : 1;
+    c->S.queue_div = 6;
+    if (const char *qd = std::getenv("RT_QUEUE_DIV")) { const int v = std::atoi(qd); if (v >= 1 && v <= 4096) c->S.queue_div = v; }
+    c->S.shaft = (no_cull || std::getenv("RT_NO_SHAFT") != nullptr) ? 0 : 1;
+    if (sc->n_nodes >= (1u << 28)) { c->err = "rt_upload_scene: more than 2^28 nodes"; return RT_ERR_UNSUPPORTED; }
     c->flat = (sc->nodes[0].count_flags & RT_NODE_LEAF) && (sc->nodes[0].count_flags & 0x7fffffffu) <= 64u;
     query_occupancy(c->flat, &c->occ_trace_primary, &c->occ_trace_rays, &c->occ_shadow, &c->occ_shade);
     // k_trace uses static tile striding: with more than ~4 blocks/CU a wave owns so few tiles (32,400 tiles at 1080p)
@@ -581,8 +593,14 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
                          c->d_best, c->d_lit, TaskQueues{nullptr, nullptr, 0u, 0u, cap, 0u});
         }
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
-        launch_shadow(count, c->flat, c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis,
-                      c->d_tasks[0], c->task_cap, c->shadow_budget, c->task_target);
+        // tree scenes with one (hit, light) pair per wave (N > 32 samples): the shaft walk (rt_kernels.hip, k_shadow_shaft)
+        const bool shaft = !c->flat && !count && c->S.shaft != 0 && L.n_samples > 32;
+        if (shaft)
+            launch_shadow_shaft(c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis,
+                                c->d_tasks[0], c->task_cap, c->shadow_budget, c->task_target);
+        else
+            launch_shadow(count, c->flat, c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis,
+                          c->d_tasks[0], c->task_cap, c->shadow_budget, c->task_target);
         if (!c->flat && !count && c->shadow_budget != 0u)      // the big leaves of the shadow units, spread over all waves
             launch_shadow_cont(c->cus * c->occ_shadow, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[0], nullptr, 2u, 0u,
                                c->task_cap, 0u);
@@ -634,7 +652,7 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
     HIPCHK(c, hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
     if (h.overflow) { c->err = "internal: a compaction list overflowed its capacity; the frame is incomplete"; return RT_ERR_HIP; }
     fold_stats(h);
-    if (std::getenv("RT_DEBUG")) std::fprintf(stderr, "RT_DEBUG level0: items %u tasks closest %u %u centre %u %u shadow %u %u\n", [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_items[0][sh * 16]; return t; }(), h.n_tasks[0][0], 0u, h.n_tasks[0][1], 0u, h.n_tasks[0][2], 0u);
+    if (std::getenv("RT_DEBUG")) std::fprintf(stderr, "RT_DEBUG level0: items %u tasks closest %u %u centre %u %u shadow %u %u\n", [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_items[0][sh * 16]; return t; }(), h.n_tasks[0][0], 0u, h.n_tasks[0][1], 0u, [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_task_sh[0][sh * 16]; return t; }(), 0u);
     out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample;
     out->pixels = F.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;
 #ifdef RT_PROFILE
@@ -646,7 +664,7 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
         for (int b = 8; b <= 30; ++b) std::fprintf(stderr, " [2^%d]=%llu", b, h.prof[16 + b]);
         std::fprintf(stderr, "\n");
         {
-            static const char *nm[8] = {"walk-other", "pop+node-load", "inner-children", "leaf-tri-mode", "leaf-scalar", "leaf-staged", "unit-setup(+queue)", "unit-finish"};
+            static const char *nm[8] = {"walk-other", "pop+node-load(shaft: group load+shaft test)", "inner-children(shaft: survivors per-ray)", "leaf-tri-mode(shaft: leaves)", "leaf-scalar", "leaf-staged", "unit-setup(+queue)", "unit-finish"};
             for (int k = 0; k < 2; ++k) {
                 unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += h.prof[72 + 8 * k + i];
                 std::fprintf(stderr, "RT_PROFILE k_shadow%s wave-cycles by phase (total %llu):", k ? "<CONT>" : "", tot);
@@ -654,6 +672,24 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
                 std::fprintf(stderr, "\n");
             }
         }
+        {
+            std::fprintf(stderr, "RT_PROFILE k_shadow_shaft waves %llu: sum of wave lifetimes %.1f us, last end - origin: see bins (50 us each):", h.prof[103], double(h.prof[102]) / 100.0);
+            for (int b = 0; b < 40; ++b) if (h.prof[110 + b]) std::fprintf(stderr, " [%d]=%llu", b, h.prof[110 + b]);
+            std::fprintf(stderr, "\n");
+        }
+        std::fprintf(stderr, "RT_PROFILE   unit durations (10 ns ticks), max %llu; log2 bins:", h.prof[559]);
+        for (int b = 0; b < 31; ++b) if (h.prof[560 + b]) std::fprintf(stderr, " [2^%d]=%llu", b, h.prof[560 + b]);
+        std::fprintf(stderr, "\n");
+        std::fprintf(stderr, "RT_PROFILE   wave START bins:");
+        for (int b = 0; b < 40; ++b) if (h.prof[520 + b]) std::fprintf(stderr, " [%d]=%llu", b, h.prof[520 + b]);
+        std::fprintf(stderr, "\n");
+        for (int x = 0; x < 8; ++x) {
+            std::fprintf(stderr, "RT_PROFILE   XCC %d (rays %llu):", x, h.prof[500 + x]);
+            for (int b = 0; b < 40; ++b) if (h.prof[160 + x * 40 + b]) std::fprintf(stderr, " [%d]=%llu", b, h.prof[160 + x * 40 + b]);
+            std::fprintf(stderr, "\n");
+        }
+        std::fprintf(stderr, "RT_PROFILE shaft walk: groups %llu children %llu shaft-survivors %llu per-ray-survivors %llu | leaf visits %llu chunks %llu shaft-kept %llu with-todo %llu\n",
+                     h.prof[88], h.prof[89], h.prof[90], h.prof[91], h.prof[92], h.prof[93], h.prof[94], h.prof[95]);
         std::fprintf(stderr, "RT_PROFILE slowest trace tile %llu: ray-mode leaf triangles %llu, tri-mode leaf triangles %llu, tri-mode (ray,chunk) tests %llu, child boxes %llu\n",
                      h.prof[56], h.prof[57], h.prof[58], h.prof[59], h.prof[60]);
         std::fprintf(stderr, "RT_PROFILE trace tiles: cycles max %llu sum %llu; log2 histogram:", h.prof[38], h.prof[39]);

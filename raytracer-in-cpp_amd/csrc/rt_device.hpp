@@ -106,7 +106,7 @@ struct alignas(16) DNode {
     float bmin[3], bmax[3];
     uint32_t first, count_flags;
     float clo[3], chi[3];
-    uint32_t pad[2];
+    uint32_t pad[2];               // pad[0]: leaves -- index of the leaf's first ChunkBound (chunks[]); pad[1]: unused
 };
 static_assert(sizeof(DNode) == 64, "DNode must be 64 bytes");
 
@@ -126,6 +126,8 @@ struct DScene {
     uint32_t n_nodes, n_faces;
     int32_t queue_local;               // k_shadow queue: -1 auto, 0 strided chunks (balance first), n chunks of n consecutive units
     int32_t plane_cull;                // k_shadow: per-unit plane culling (rt_kernels.hip, SegPacket); RT_NO_PLANE_CULL=1 turns it off
+    int32_t queue_div;                 // k_shadow_shaft: units are handed out in chunks of units / (waves x queue_div)
+    int32_t shaft;                     // k_shadow on tree scenes: shaft-culled group walk (rt_kernels.hip, shaft_walk); RT_NO_SHAFT=1 turns it off
 };
 
 struct DCam {
@@ -172,7 +174,10 @@ struct Control {
     uint32_t queue[3 * (RT_MAX_DEPTH + 1) + 4][RT_QUEUE_SHARDS * 16];
     uint32_t n_items[RT_MAX_DEPTH + 1][RT_LIST_SHARDS * 16];   // lit hits per level and shard (counter s at [s * 16])
     uint32_t n_rays[RT_MAX_DEPTH + 2][RT_LIST_SHARDS * 16];    // bounce rays per level and shard (n_rays[0][0] = rt_trace_rays input count)
-    uint32_t n_tasks[RT_MAX_DEPTH + 1][4];           // leaf tasks per level: closest q0 | centre q1 | shadow q2 | (spare)
+    uint32_t n_tasks[RT_MAX_DEPTH + 1][4];           // leaf tasks per level: closest q0 | centre q1 | (shadow: n_task_sh) | (spare)
+    // leaf tasks of the shadow kernels: RT_LIST_SHARDS sub-queues (producer block % RT_LIST_SHARDS), each counter on its own line --
+    // one returning atomic per emitting leaf visit on a SINGLE word (~60k per dodge launch) ran into the ~88 per us limit
+    uint32_t n_task_sh[RT_MAX_DEPTH + 1][RT_LIST_SHARDS * 16];
     uint32_t overflow;                               // set by a kernel whose list reservation did not fit (never expected: the
                                                      // capacities are derived from the tile counts); the host turns it into an error
     // totals, filled on the HOST by fold_stats() from the sharded counters below
@@ -184,7 +189,7 @@ struct Control {
     // whose arithmetic needs < 20 us.)
     unsigned long long stat[RT_STAT_SHARDS][16];
     // -DRT_PROFILE builds only: executed work (wave steps) and useful lane work per leaf mode / box tests
-    unsigned long long prof[96];
+    unsigned long long prof[640];
 };
 
 inline void fold_stats(Control &h) {

@@ -125,9 +125,9 @@ struct ShardedQueue {
         ctr = nullptr; total = 0u; lane = ln; chunk = 1u; nchunks = total_waves; shard = 0; tries = 0; fetched = 0;
         cur = wave_id; cur_end = total_units;
     }
-    __device__ __forceinline__ void init(uint32_t *heads, uint32_t total_units, uint32_t total_waves, uint32_t home, int ln, uint32_t local_chunk = 0u) {
+    __device__ __forceinline__ void init(uint32_t *heads, uint32_t total_units, uint32_t total_waves, uint32_t home, int ln, uint32_t local_chunk = 0u, uint32_t div = 6u) {
         ctr = heads; total = total_units; lane = ln; local = local_chunk;
-        chunk = total_units / (total_waves * 6u);
+        chunk = total_units / (total_waves * div);
         if (chunk < 1u) chunk = 1u;
         if (local) chunk = local;
         nchunks = (total_units + chunk - 1u) / chunk;          // chunk c = { c + j * nchunks }   (local: { c * chunk + j })
@@ -184,6 +184,9 @@ __device__ uint32_t g_wave_steps[4];     // diagnostic: written by the wave that
 #define RT_TILE_COUNT(stk, lane, idx, val) do { } while (0)
 #endif
 #define RT_STAGE_TRIS 64
+#ifndef RT_LDS_NODES
+#define RT_LDS_NODES 256        // DNodes of the top of the tree kept in LDS by k_shadow (16 KB per block)
+#endif
 #define RT_SCALAR_LEAF_MAX 16   // leaves up to this size are walked with scalar loads straight from the scalar cache
 
 // Wave-uniform octree walk for 64 rays.
@@ -371,7 +374,222 @@ struct PhaseClock {
 #define RT_COST_TRI_MODE 58u      // per (active ray, 64-triangle chunk), lanes = triangles
 #define RT_COST_CHUNK_TEST 30u    // per chunk: conservative bound test for all 64 rays at once
 
-template <bool ANY, bool COUNT>
+// One leaf of a packet walk: every triangle of the leaf is a candidate for the rays in `live` (BoxTree::intersect inserts all faces of an
+// intersected leaf, boxTree.cpp:158-160).  Shared by the stack walk (packet_walk) and the shaft-culled breadth-first walk of the shadow units.
+struct RayLane {
+    float ox, oy, oz;        // origin
+    float dx, dy, dz;        // triangle-test direction
+    float idx, idy, idz;     // v_rcp_f32 of the box-test direction (conservative tests only)
+    float slab_pad;
+};
+template <bool ANY, bool COUNT, bool STAGED = true>
+__device__ __forceinline__ void leaf_visit(const DNode &nd, const uint32_t ni, const TriRec *__restrict__ tris, const ChunkBound *__restrict__ chunks,
+                                           const uint32_t *__restrict__ leaf_chunk0, const WaveStack stk, const int lane, const WalkCtl &wc,
+                                           const RayLane &R, unsigned long long live, bool mine,
+                                           float &best_t, int &best_f, bool &occluded, uint32_t &cnt_ref) {
+    const float ox = R.ox, oy = R.oy, oz = R.oz, dx = R.dx, dy = R.dy, dz = R.dz;
+    const float idx_ = R.idx, idy_ = R.idy, idz_ = R.idz, slab_pad = R.slab_pad;
+    const uint32_t cnt = nd.count_flags & 0x7fffffffu;
+    if (COUNT && mine) cnt_ref += cnt;
+    const TriRec *__restrict__ T = tris + nd.first;
+    const uint32_t nchunk = (cnt + 63u) >> 6;
+    // lanes=triangles estimate: one bound test per chunk + live rays x the share of chunks a ray cannot skip
+    // STAGED = false (kernels without the LDS staging buffer): leaves too large for the scalar-load walk always take lanes = triangles
+    const bool tri_mode = (!STAGED && cnt > RT_SCALAR_LEAF_MAX) ||
+                          nchunk * RT_COST_CHUNK_TEST + static_cast<uint32_t>(__popcll(live)) * ((nchunk + 2u) / 3u) * RT_COST_TRI_MODE
+                          < cnt * RT_COST_RAY_MODE;
+    const uint32_t est = tri_mode ? nchunk * RT_COST_CHUNK_TEST + static_cast<uint32_t>(__popcll(live)) * ((nchunk + 2u) / 3u) * RT_COST_TRI_MODE
+                                  : cnt * RT_COST_RAY_MODE;
+    uint32_t cb = 0u, ce = nchunk;                       // chunk range processed here
+    if (wc.resume) {
+        cb = wc.c_begin; ce = wc.c_end < nchunk ? wc.c_end : nchunk;
+    } else if (wc.budget != 0u && est > wc.budget) {
+        // hand the leaf away as ~target-instruction pieces (whole chunks); one atomic reserves the slots
+        uint32_t ntask = (est + wc.target - 1u) / wc.target;
+        if (ntask > nchunk) ntask = nchunk;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(wc.task_count, ntask);
+        base = uniform_u32(base);
+        // The counter only ever grows (the consumer clamps it to the capacity): pieces that fall past the end of the
+        // queue are simply processed here.  (Giving a failed reservation back with an atomicSub is unsound: a later
+        // reservation can land inside the window and end up beyond the final count.)
+        const uint32_t fit = base >= wc.task_cap ? 0u : (ntask < wc.task_cap - base ? ntask : wc.task_cap - base);
+        for (uint32_t i = static_cast<uint32_t>(lane); i < fit; i += 64u) {
+            ContTask t;
+            t.unit = wc.unit; t.node = ni; t.mask = live;
+            t.c_begin = static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * i / ntask);
+            t.c_end = static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * (i + 1u) / ntask);
+            t.pad0 = t.pad1 = 0u;
+            wc.tasks[base + i] = t;
+        }
+        if (fit == ntask) return;
+        cb = static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * fit / ntask);       // the rest of the leaf, inline
+    }
+    RT_PROF_ADD(lane, tri_mode ? 7 : 6, 1);
+    RT_TILE_COUNT(stk, lane, tri_mode ? 1 : 0, cnt);
+    RT_PH(wc, tri_mode ? 3 : (cnt <= RT_SCALAR_LEAF_MAX ? 4 : 5));
+    if (tri_mode) {
+        RT_PROF_ADD(lane, 8, __popcll(live));
+        // ---- lanes = triangles.  Each lane keeps ONE leaf triangle in registers (coalesced 80-B records, next
+        // chunk prefetched); the active rays are broadcast one at a time with v_readlane and every lane tests
+        // its triangle against that ray.  A ballot reports the hits: exact early-out per ray for shadow rays,
+        // and a scalar pick of the (t, face) minimum for closest hit.  No per-triangle memory round trip.
+        unsigned long long occ_new = 0ull;
+        const ChunkBound *__restrict__ cbounds = chunks + nd.pad[0];      // first chunk bound of the leaf (rt_capi.cpp: DNode.pad[0])
+        // per-ray quantities of the conservative chunk test (approximate arithmetic is fine: they only ever SKIP
+        // work); computed per leaf visit so that scenes that never take this mode (the cube) pay nothing
+        const uint32_t t_end = ce * 64u < cnt ? ce * 64u : cnt;
+        TriRec tr = T[cb * 64u + static_cast<uint32_t>(lane) < cnt ? cb * 64u + static_cast<uint32_t>(lane) : 0u];
+        for (uint32_t c0 = cb * 64u; c0 < t_end; c0 += 64u) {
+            const uint32_t n = cnt - c0 < 64u ? cnt - c0 : 64u;
+            const bool has = static_cast<uint32_t>(lane) < n && !(ANY && (tr.flags & 1u));
+            const uint32_t nx = c0 + 64u + static_cast<uint32_t>(lane);
+            const TriRec nxt = T[nx < cnt ? nx : 0u];                      // prefetch (uniformly skipped work is cheap)
+            // conservative chunk test (lanes = rays): a live ray skips the chunk when no point of its line that a hit could
+            // count at lies in the chunk's inflated box (rt_capi.cpp, build_chunk_bounds, has the error analysis)
+            unsigned long long todo = live;
+            {
+                const ChunkBound bd = cbounds[c0 >> 6];
+                if (bd.never < 1.5f) {
+                    const float t0x = (bd.lo[0] - slab_pad - ox) * idx_, t1x = (bd.hi[0] + slab_pad - ox) * idx_;
+                    const float t0y = (bd.lo[1] - slab_pad - oy) * idy_, t1y = (bd.hi[1] + slab_pad - oy) * idy_;
+                    const float t0z = (bd.lo[2] - slab_pad - oz) * idz_, t1z = (bd.hi[2] + slab_pad - oz) * idz_;
+                    const float tin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+                    const float tout = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+                    // the line misses the box, or only meets it where no hit can count: behind the origin (t <= 0.00001 is
+                    // never accepted), and beyond 0.98 for a shadow ray / beyond the current closest hit otherwise
+                    // (t of an accepted hit lies in [tin, tout] up to ~1e-6 relative: its point is inside the padded box)
+                    const bool miss = (tin > tout) || (tout < -1e-3f) ||
+                                      (ANY ? (tin > 0.981f) : (tin > best_t + 1e-3f * (1.0f + fabsf(best_t))));
+                    const unsigned long long culled = __ballot(miss) & live;
+                    todo = live & ~culled;
+                    RT_PROF_ADD(lane, 14, __popcll(culled));
+                }
+            }
+            // step 3 (lanes = triangles): full test of the surviving rays, two rays per step for ILP (two independent
+            // division chains in flight)
+            while (todo != 0ull) {
+                const int r0 = static_cast<int>(__builtin_ctzll(todo));
+                todo &= todo - 1ull;
+                const bool two = todo != 0ull;
+                const int r1 = two ? static_cast<int>(__builtin_ctzll(todo)) : r0;
+                if (two) todo &= todo - 1ull;
+                RT_PROF_ADD(lane, 2, two ? 2 : 1); RT_PROF_ADD(lane, 3, (two ? 2 : 1) * __popcll(__ballot(has)));
+                RT_TILE_COUNT(stk, lane, 2, two ? 2 : 1);
+                // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 (same operations as the ray-lane form)
+                float tq[2]; bool inq[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int r = q == 0 ? r0 : r1;
+                    const float rdx = lane_f(dx, r), rdy = lane_f(dy, r), rdz = lane_f(dz, r);
+                    const float rox = lane_f(ox, r), roy = lane_f(oy, r), roz = lane_f(oz, r);
+                    const float dn = dot3(rdx, rdy, rdz, tr.nx, tr.ny, tr.nz);
+                    const float t = (tr.nA - dot3(rox, roy, roz, tr.nx, tr.ny, tr.nz)) / dn;
+                    const float v2x = (rox + t * rdx) - tr.ax, v2y = (roy + t * rdy) - tr.ay, v2z = (roz + t * rdz) - tr.az;
+                    const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
+                    const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
+                    const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
+                    const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
+                    tq[q] = t;
+                    inq[q] = has && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f);
+                }
+                if (!two) inq[1] = false;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int r = q == 0 ? r0 : r1;
+                    if (ANY) {
+                        if (__ballot(inq[q] && tq[q] < 0.98f) != 0ull) {
+                            occ_new |= 1ull << r;
+                            if (!COUNT) live &= ~(1ull << r);
+                        }
+                    } else {
+                        unsigned long long hm = __ballot(inq[q]);
+                        if (hm != 0ull) {
+                            float bt = lane_f(best_t, r);
+                            int bf = __builtin_amdgcn_readlane(best_f, r);
+                            do {
+                                const int l = static_cast<int>(__builtin_ctzll(hm));
+                                hm &= hm - 1ull;
+                                const float tl = lane_f(tq[q], l);
+                                const int fl = __builtin_amdgcn_readlane(static_cast<int>(tr.face), l);
+                                if (tl < bt || (tl == bt && fl < bf)) { bt = tl; bf = fl; }
+                            } while (hm != 0ull);
+                            if (lane == r) { best_t = bt; best_f = bf; }
+                        }
+                    }
+                }
+            }
+            if (ANY && !COUNT && live == 0ull) break;
+            tr = nxt;
+        }
+        if (ANY) occluded = occluded || (((occ_new >> lane) & 1ull) != 0ull);
+    } else {
+        // ---- lanes = rays: every lane steps through the leaf's triangles for its own ray.
+        // Small leaves: the records are wave-uniform scalar loads (s_load_dwordx16 + x4, scalar cache).
+        // Larger leaves: 64-triangle chunks are staged into this wave's LDS buffer with coalesced 16-byte
+        // loads (ONE memory round trip per chunk instead of one per triangle), then read back as LDS
+        // broadcasts (all lanes the same address), software-pipelined one record ahead.
+        auto test_lane = [&](const TriRec &tr) {
+            // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 (straight-line form, see flat_walk)
+            const float dn = dot3(dx, dy, dz, tr.nx, tr.ny, tr.nz);
+            const float t = (tr.nA - dot3(ox, oy, oz, tr.nx, tr.ny, tr.nz)) / dn;
+            const float v2x = (ox + t * dx) - tr.ax, v2y = (oy + t * dy) - tr.ay, v2z = (oz + t * dz) - tr.az;
+            const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
+            const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
+            const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
+            const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
+            const bool ok = mine && !(ANY && (tr.flags & 1u)) && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f);
+            if (ANY) {
+                occluded = occluded || (ok && t < 0.98f);
+            } else {
+                const bool better = ok && (t < best_t || (t == best_t && static_cast<int>(tr.face) < best_f));
+                best_t = better ? t : best_t;
+                best_f = better ? static_cast<int>(tr.face) : best_f;
+            }
+        };
+        if (cnt <= RT_SCALAR_LEAF_MAX) {
+            uint32_t k = 0;
+            for (; k + 1u < cnt; k += 2u) {
+                TriRec ta, tb;
+                tri_load_uniform2(T + k, ta, tb);
+                RT_PROF_ADD(lane, 0, 2); RT_PROF_ADD(lane, 1, 2 * __popcll(__ballot(mine)));
+                test_lane(ta);
+                test_lane(tb);
+            }
+            if (k < cnt) {
+                RT_PROF_ADD(lane, 0, 1); RT_PROF_ADD(lane, 1, __popcll(__ballot(mine)));
+                test_lane(tri_load_uniform(T + k));
+            }
+        } else if (STAGED) {
+            const uint32_t r_end = ce * 64u < cnt ? ce * 64u : cnt;
+            for (uint32_t c0 = cb * 64u; c0 < r_end; c0 += RT_STAGE_TRIS) {
+                const uint32_t n = cnt - c0 < RT_STAGE_TRIS ? cnt - c0 : RT_STAGE_TRIS;
+                const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(T + c0);
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t q = static_cast<uint32_t>(lane); q < n * 5u; q += 64u) stk.stage[q] = src[q];
+                __builtin_amdgcn_wave_barrier();
+                const TriRec *staged = reinterpret_cast<const TriRec *>(stk.stage);
+                uint32_t k = 0;
+                for (; k + 1u < n; k += 2u) {       // two records per step: two independent chains in flight
+                    const TriRec ta = staged[k], tb = staged[k + 1u];
+                    RT_PROF_ADD(lane, 0, 2); RT_PROF_ADD(lane, 1, 2 * __popcll(__ballot(mine)));
+                    test_lane(ta);
+                    test_lane(tb);
+                }
+                if (k < n) {
+                    RT_PROF_ADD(lane, 0, 1); RT_PROF_ADD(lane, 1, __popcll(__ballot(mine)));
+                    test_lane(staged[k]);
+                }
+                if (ANY && !COUNT) {
+                    mine = mine && !occluded;
+                    if (__ballot(mine) == 0ull) break;
+                }
+            }
+        }
+    }
+}
+
+template <bool ANY, bool COUNT, bool STAGED = true>
 __device__ __forceinline__ void packet_walk(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris,
                                             const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                             const float extent, const WaveStack stk, const int lane, const WalkCtl wc, bool in_root,
@@ -410,201 +628,8 @@ __device__ __forceinline__ void packet_walk(const DNode *__restrict__ nodes, con
         const DNode nd = nodes[ni];
         const uint32_t cnt = nd.count_flags & 0x7fffffffu;
         if (nd.count_flags & RT_NODE_LEAF) {
-            if (COUNT && mine) cnt_ref += cnt;
-            const TriRec *__restrict__ T = tris + nd.first;
-            const uint32_t nchunk = (cnt + 63u) >> 6;
-            // lanes=triangles estimate: one bound test per chunk + live rays x the share of chunks a ray cannot skip
-            const bool tri_mode = nchunk * RT_COST_CHUNK_TEST + static_cast<uint32_t>(__popcll(live)) * ((nchunk + 2u) / 3u) * RT_COST_TRI_MODE
-                                  < cnt * RT_COST_RAY_MODE;
-            const uint32_t est = tri_mode ? nchunk * RT_COST_CHUNK_TEST + static_cast<uint32_t>(__popcll(live)) * ((nchunk + 2u) / 3u) * RT_COST_TRI_MODE
-                                          : cnt * RT_COST_RAY_MODE;
-            uint32_t cb = 0u, ce = nchunk;                       // chunk range processed here
-            if (wc.resume) {
-                cb = wc.c_begin; ce = wc.c_end < nchunk ? wc.c_end : nchunk;
-            } else if (wc.budget != 0u && est > wc.budget) {
-                // hand the leaf away as ~target-instruction pieces (whole chunks); one atomic reserves the slots
-                uint32_t ntask = (est + wc.target - 1u) / wc.target;
-                if (ntask > nchunk) ntask = nchunk;
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(wc.task_count, ntask);
-                base = uniform_u32(base);
-                // The counter only ever grows (the consumer clamps it to the capacity): pieces that fall past the end of the
-                // queue are simply processed here.  (Giving a failed reservation back with an atomicSub is unsound: a later
-                // reservation can land inside the window and end up beyond the final count.)
-                const uint32_t fit = base >= wc.task_cap ? 0u : (ntask < wc.task_cap - base ? ntask : wc.task_cap - base);
-                for (uint32_t i = static_cast<uint32_t>(lane); i < fit; i += 64u) {
-                    ContTask t;
-                    t.unit = wc.unit; t.node = ni; t.mask = live;
-                    t.c_begin = static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * i / ntask);
-                    t.c_end = static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * (i + 1u) / ntask);
-                    t.pad0 = t.pad1 = 0u;
-                    wc.tasks[base + i] = t;
-                }
-                if (fit == ntask) continue;
-                cb = static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * fit / ntask);       // the rest of the leaf, inline
-            }
-            RT_PROF_ADD(lane, tri_mode ? 7 : 6, 1);
-            RT_TILE_COUNT(stk, lane, tri_mode ? 1 : 0, cnt);
-            RT_PH(wc, tri_mode ? 3 : (cnt <= RT_SCALAR_LEAF_MAX ? 4 : 5));
-            if (tri_mode) {
-                RT_PROF_ADD(lane, 8, __popcll(live));
-                // ---- lanes = triangles.  Each lane keeps ONE leaf triangle in registers (coalesced 80-B records, next
-                // chunk prefetched); the active rays are broadcast one at a time with v_readlane and every lane tests
-                // its triangle against that ray.  A ballot reports the hits: exact early-out per ray for shadow rays,
-                // and a scalar pick of the (t, face) minimum for closest hit.  No per-triangle memory round trip.
-                unsigned long long occ_new = 0ull;
-                const ChunkBound *__restrict__ cbounds = chunks + leaf_chunk0[ni];
-                // per-ray quantities of the conservative chunk test (approximate arithmetic is fine: they only ever SKIP
-                // work); computed per leaf visit so that scenes that never take this mode (the cube) pay nothing
-                const uint32_t t_end = ce * 64u < cnt ? ce * 64u : cnt;
-                TriRec tr = T[cb * 64u + static_cast<uint32_t>(lane) < cnt ? cb * 64u + static_cast<uint32_t>(lane) : 0u];
-                for (uint32_t c0 = cb * 64u; c0 < t_end; c0 += 64u) {
-                    const uint32_t n = cnt - c0 < 64u ? cnt - c0 : 64u;
-                    const bool has = static_cast<uint32_t>(lane) < n && !(ANY && (tr.flags & 1u));
-                    const uint32_t nx = c0 + 64u + static_cast<uint32_t>(lane);
-                    const TriRec nxt = T[nx < cnt ? nx : 0u];                      // prefetch (uniformly skipped work is cheap)
-                    // conservative chunk test (lanes = rays): a live ray skips the chunk when no point of its line that a hit could
-                    // count at lies in the chunk's inflated box (rt_capi.cpp, build_chunk_bounds, has the error analysis)
-                    unsigned long long todo = live;
-                    {
-                        const ChunkBound bd = cbounds[c0 >> 6];
-                        if (bd.never < 1.5f) {
-                            const float t0x = (bd.lo[0] - slab_pad - ox) * idx_, t1x = (bd.hi[0] + slab_pad - ox) * idx_;
-                            const float t0y = (bd.lo[1] - slab_pad - oy) * idy_, t1y = (bd.hi[1] + slab_pad - oy) * idy_;
-                            const float t0z = (bd.lo[2] - slab_pad - oz) * idz_, t1z = (bd.hi[2] + slab_pad - oz) * idz_;
-                            const float tin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-                            const float tout = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-                            // the line misses the box, or only meets it where no hit can count: behind the origin (t <= 0.00001 is
-                            // never accepted), and beyond 0.98 for a shadow ray / beyond the current closest hit otherwise
-                            // (t of an accepted hit lies in [tin, tout] up to ~1e-6 relative: its point is inside the padded box)
-                            const bool miss = (tin > tout) || (tout < -1e-3f) ||
-                                              (ANY ? (tin > 0.981f) : (tin > best_t + 1e-3f * (1.0f + fabsf(best_t))));
-                            const unsigned long long culled = __ballot(miss) & live;
-                            todo = live & ~culled;
-                            RT_PROF_ADD(lane, 14, __popcll(culled));
-                        }
-                    }
-                    // step 3 (lanes = triangles): full test of the surviving rays, two rays per step for ILP (two independent
-                    // division chains in flight)
-                    while (todo != 0ull) {
-                        const int r0 = static_cast<int>(__builtin_ctzll(todo));
-                        todo &= todo - 1ull;
-                        const bool two = todo != 0ull;
-                        const int r1 = two ? static_cast<int>(__builtin_ctzll(todo)) : r0;
-                        if (two) todo &= todo - 1ull;
-                        RT_PROF_ADD(lane, 2, two ? 2 : 1); RT_PROF_ADD(lane, 3, (two ? 2 : 1) * __popcll(__ballot(has)));
-                        RT_TILE_COUNT(stk, lane, 2, two ? 2 : 1);
-                        // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 (same operations as the ray-lane form)
-                        float tq[2]; bool inq[2];
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const int r = q == 0 ? r0 : r1;
-                            const float rdx = lane_f(dx, r), rdy = lane_f(dy, r), rdz = lane_f(dz, r);
-                            const float rox = lane_f(ox, r), roy = lane_f(oy, r), roz = lane_f(oz, r);
-                            const float dn = dot3(rdx, rdy, rdz, tr.nx, tr.ny, tr.nz);
-                            const float t = (tr.nA - dot3(rox, roy, roz, tr.nx, tr.ny, tr.nz)) / dn;
-                            const float v2x = (rox + t * rdx) - tr.ax, v2y = (roy + t * rdy) - tr.ay, v2z = (roz + t * rdz) - tr.az;
-                            const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
-                            const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
-                            const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
-                            const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
-                            tq[q] = t;
-                            inq[q] = has && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f);
-                        }
-                        if (!two) inq[1] = false;
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const int r = q == 0 ? r0 : r1;
-                            if (ANY) {
-                                if (__ballot(inq[q] && tq[q] < 0.98f) != 0ull) {
-                                    occ_new |= 1ull << r;
-                                    if (!COUNT) live &= ~(1ull << r);
-                                }
-                            } else {
-                                unsigned long long hm = __ballot(inq[q]);
-                                if (hm != 0ull) {
-                                    float bt = lane_f(best_t, r);
-                                    int bf = __builtin_amdgcn_readlane(best_f, r);
-                                    do {
-                                        const int l = static_cast<int>(__builtin_ctzll(hm));
-                                        hm &= hm - 1ull;
-                                        const float tl = lane_f(tq[q], l);
-                                        const int fl = __builtin_amdgcn_readlane(static_cast<int>(tr.face), l);
-                                        if (tl < bt || (tl == bt && fl < bf)) { bt = tl; bf = fl; }
-                                    } while (hm != 0ull);
-                                    if (lane == r) { best_t = bt; best_f = bf; }
-                                }
-                            }
-                        }
-                    }
-                    if (ANY && !COUNT && live == 0ull) break;
-                    tr = nxt;
-                }
-                if (ANY) occluded = occluded || (((occ_new >> lane) & 1ull) != 0ull);
-            } else {
-                // ---- lanes = rays: every lane steps through the leaf's triangles for its own ray.
-                // Small leaves: the records are wave-uniform scalar loads (s_load_dwordx16 + x4, scalar cache).
-                // Larger leaves: 64-triangle chunks are staged into this wave's LDS buffer with coalesced 16-byte
-                // loads (ONE memory round trip per chunk instead of one per triangle), then read back as LDS
-                // broadcasts (all lanes the same address), software-pipelined one record ahead.
-                auto test_lane = [&](const TriRec &tr) {
-                    // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 (straight-line form, see flat_walk)
-                    const float dn = dot3(dx, dy, dz, tr.nx, tr.ny, tr.nz);
-                    const float t = (tr.nA - dot3(ox, oy, oz, tr.nx, tr.ny, tr.nz)) / dn;
-                    const float v2x = (ox + t * dx) - tr.ax, v2y = (oy + t * dy) - tr.ay, v2z = (oz + t * dz) - tr.az;
-                    const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
-                    const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
-                    const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
-                    const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
-                    const bool ok = mine && !(ANY && (tr.flags & 1u)) && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f);
-                    if (ANY) {
-                        occluded = occluded || (ok && t < 0.98f);
-                    } else {
-                        const bool better = ok && (t < best_t || (t == best_t && static_cast<int>(tr.face) < best_f));
-                        best_t = better ? t : best_t;
-                        best_f = better ? static_cast<int>(tr.face) : best_f;
-                    }
-                };
-                if (cnt <= RT_SCALAR_LEAF_MAX) {
-                    uint32_t k = 0;
-                    for (; k + 1u < cnt; k += 2u) {
-                        TriRec ta, tb;
-                        tri_load_uniform2(T + k, ta, tb);
-                        RT_PROF_ADD(lane, 0, 2); RT_PROF_ADD(lane, 1, 2 * __popcll(__ballot(mine)));
-                        test_lane(ta);
-                        test_lane(tb);
-                    }
-                    if (k < cnt) {
-                        RT_PROF_ADD(lane, 0, 1); RT_PROF_ADD(lane, 1, __popcll(__ballot(mine)));
-                        test_lane(tri_load_uniform(T + k));
-                    }
-                } else {
-                    const uint32_t r_end = ce * 64u < cnt ? ce * 64u : cnt;
-                    for (uint32_t c0 = cb * 64u; c0 < r_end; c0 += RT_STAGE_TRIS) {
-                        const uint32_t n = cnt - c0 < RT_STAGE_TRIS ? cnt - c0 : RT_STAGE_TRIS;
-                        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(T + c0);
-                        __builtin_amdgcn_wave_barrier();
-                        for (uint32_t q = static_cast<uint32_t>(lane); q < n * 5u; q += 64u) stk.stage[q] = src[q];
-                        __builtin_amdgcn_wave_barrier();
-                        const TriRec *staged = reinterpret_cast<const TriRec *>(stk.stage);
-                        uint32_t k = 0;
-                        for (; k + 1u < n; k += 2u) {       // two records per step: two independent chains in flight
-                            const TriRec ta = staged[k], tb = staged[k + 1u];
-                            RT_PROF_ADD(lane, 0, 2); RT_PROF_ADD(lane, 1, 2 * __popcll(__ballot(mine)));
-                            test_lane(ta);
-                            test_lane(tb);
-                        }
-                        if (k < n) {
-                            RT_PROF_ADD(lane, 0, 1); RT_PROF_ADD(lane, 1, __popcll(__ballot(mine)));
-                            test_lane(staged[k]);
-                        }
-                        if (ANY && !COUNT) {
-                            mine = mine && !occluded;
-                            if (__ballot(mine) == 0ull) break;
-                        }
-                    }
-                }
-            }
+            leaf_visit<ANY, COUNT, STAGED>(nd, ni, tris, chunks, leaf_chunk0, stk, lane, wc, RayLane{ox, oy, oz, dx, dy, dz, idx_, idy_, idz_, slab_pad}, live, mine,
+                                   best_t, best_f, occluded, cnt_ref);
         } else {
             RT_TILE_COUNT(stk, lane, 3, cnt);
             RT_PH(wc, 2);
@@ -612,7 +637,7 @@ __device__ __forceinline__ void packet_walk(const DNode *__restrict__ nodes, con
                 const uint32_t ci = nd.first + c;
                 const DNode ch = nodes[ci];
                 bool h = mine;
-                if (!COUNT) {
+                if (!COUNT && ch.pad[1] == 0u) {         // pad[1]: a never-cullable chunk below -> the content box only bounds the rest
                     // content test first (it is the cheaper one and rules out most children): no countable point of the line
                     // inside the subtree's content box -> nothing below can be hit, whatever the reference's box test says
                     const float t0x = (ch.clo[0] - slab_pad - ox) * idx_, t1x = (ch.chi[0] + slab_pad - ox) * idx_;
@@ -715,7 +740,7 @@ __device__ __forceinline__ void flat_walk(const DNode &root, const TriRec *__res
     if (k < cnt) test_one(tri_load_uniform(T + k));
 }
 
-template <bool ANY, bool COUNT, bool FLAT>
+template <bool ANY, bool COUNT, bool FLAT, bool STAGED = true>
 __device__ __forceinline__ void walk(const DNode &root, const DNode *__restrict__ nodes, const TriRec *__restrict__ tris,
                                      const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                      const float extent, const WaveStack stk, const int lane, const WalkCtl wc, const LanePlane &pl, bool in_root,
@@ -724,8 +749,367 @@ __device__ __forceinline__ void walk(const DNode &root, const DNode *__restrict_
                                      const float brx, const float bry, const float brz,
                                      float &best_t, int &best_f, bool &occluded, uint32_t &cnt_box, uint32_t &cnt_ref) {
     if (FLAT) flat_walk<ANY, COUNT>(root, tris, in_root, wc.seg, pl, ox, oy, oz, dx, dy, dz, best_t, best_f, occluded, cnt_box, cnt_ref);
-    else packet_walk<ANY, COUNT>(nodes, tris, chunks, leaf_chunk0, extent, stk, lane, wc, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz,
+    else packet_walk<ANY, COUNT, STAGED>(nodes, tris, chunks, leaf_chunk0, extent, stk, lane, wc, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz,
                                  brx, bry, brz, best_t, best_f, occluded, cnt_box, cnt_ref);
+}
+
+// ======================================================================================================
+// SHAFT WALK -- the traversal of a shadow unit (k_shadow_shaft: one (hit, light) pair -- or one 64-sample pass of it -- per wave).
+//
+// All 64 segments of the unit end at the shaded hit point h and start inside the box S of the unit's light samples: they lie in the
+// SHAFT hull(S, h).  A counted hit (0.00001 < t < 0.98) has its computed point inside the inflated chunk box it belongs to
+// (rt_capi.cpp, build_chunk_bounds) and on its segment up to rounding, so a node whose CONTENT box (padded like the per-ray
+// content test) does not meet the shaft cannot contribute to any ray of the unit -- whatever the reference's own box tests say.
+// And a node whose OWN box (padded) misses every point a ray of the unit can reach -- the shaft and the FAR cone behind h, the
+// rays continue beyond the hit point: boxIntersect has no upper bound -- fails the reference's boxIntersect for every ray of the
+// unit by a margin far above the rounding of its float slab test, so no ray enters the subtree.
+//
+// The shaft test runs with LANE = (CHILD, TEST): the 8 children of an inner node x 8 separating tests (six tangent planes through
+// h -- two per axis-aligned projection; the x-z and y-z pairs are the side faces of the pyramid over an axis-aligned light
+// rectangle -- plus the near and the far bounding box) take ONE wave step; each lane keeps its test's coefficients in registers for
+// the whole unit.  Only the surviving children are tested per ray (lane = ray) with the reference's exact boxIntersect; their
+// records are broadcast with v_readlane from the lanes that loaded them (no second memory round trip).  The top of the tree is
+// read from LDS (the first RT_LDS_NODES DNodes of the breadth-first array), the rest from global memory.  Leaves found by the
+// walk are processed afterwards, chunk bounds again with lane = (chunk, test).
+// The candidate set of every ray is unchanged: leaves are still entered only through the per-ray exact tests of the whole
+// ancestor chain (BoxTree::intersect, boxTree.cpp:150-173).
+// ======================================================================================================
+struct ShaftLanes {
+    float r[8];          // this lane's test (lane & 7): planes 0-5 (ax+, ax-, ay+, ay-, az+, az-, c, 2*margin); 6: near box (lo, hi); 7: far box
+    float pad;           // padding of the tested boxes (>= the per-ray slab_pad of every segment of the unit); wave-uniform
+    bool node_ok;        // the node-box test is valid: no ray of the unit has a zero / non-finite direction component (0/0 = NaN makes
+                         // the reference's min/max chain ACCEPT whatever the geometry says)
+};
+
+// lane & 7 = test index.  The tangent lines from h to the rectangle S are computed in the projection the lane's plane belongs to:
+// planes 0,1 (x,z), 2,3 (y,z), 4,5 (x,y); a line a*u + b*v + c = 0 through h with S on its non-positive side, given as the plane
+// (ax, ay, az, c) with the third coefficient zero and split into positive / negative parts, so that
+//      min over the corners of a box = ax+ * lx + ax- * hx + ay+ * ly + ay- * hy + az+ * lz + az- * hz + c      (max: lo <-> hi)
+__device__ __forceinline__ ShaftLanes make_shaft_lanes(const int lane, const float hx, const float hy, const float hz, const float slx, const float sly,
+                                                       const float slz, const float shx, const float shy, const float shz, const float extent) {
+    ShaftLanes SL;
+    const int tk = lane & 7, proj = tk >> 1;
+    const bool q1 = (tk & 1) != 0;
+    const float big = fmaxf(fmaxf(fabsf(slx), fabsf(shx)), fmaxf(fabsf(sly), fabsf(shy))) + fmaxf(fabsf(slz), fabsf(shz));
+    const float scale = extent + big + (fabsf(hx) + fabsf(hy) + fabsf(hz));
+    // per-ray slab_pad = 4e-4 * (|o|_1 + extent) with o inside S
+    SL.pad = 4e-4f * ((fmaxf(fabsf(slx), fabsf(shx)) + fmaxf(fabsf(sly), fabsf(shy)) + fmaxf(fabsf(slz), fabsf(shz))) + extent) * 1.001f;
+    SL.node_ok = true;
+    const float hu = proj == 1 ? hy : hx, hv = proj == 2 ? hy : hz;
+    const float u0 = proj == 1 ? sly : slx, u1 = proj == 1 ? shy : shx;
+    const float v0 = proj == 2 ? sly : slz, v1 = proj == 2 ? shy : shz;
+    const bool ul = hu < u0, ur = hu > u1, vl = hv < v0, vr = hv > v1;
+    const bool su0 = !(ul || ur), sv0 = !(vl || vr);
+    const float near_u = ul ? u0 : u1, far_u = ul ? u1 : u0, near_v = vl ? v0 : v1, far_v = vl ? v1 : v0;
+    // the two tangent corners of the rectangle seen from h (q = 0 / 1)
+    const float cu = q1 ? (su0 ? u1 : (sv0 ? near_u : far_u)) : (su0 ? u0 : near_u);
+    const float cv = q1 ? (sv0 ? v1 : near_v) : (sv0 ? v0 : (su0 ? near_v : far_v));
+    const float mu = 0.5f * (u0 + u1) - hu, mv = 0.5f * (v0 + v1) - hv;        // rectangle centre relative to h
+    const float nu = -(cv - hv), nv = cu - hu;
+    const float fm = nu * mu + nv * mv;
+    const float mag = fabsf(nu) + fabsf(nv);
+    // usable: h outside the rectangle and the centre strictly on one side (a degenerate rectangle in line with h has no tangent)
+    const bool ok = !(su0 && sv0) && (fabsf(fm) > 1e-5f * mag * scale);
+    const float sgn = fm > 0.0f ? -1.0f : 1.0f;
+    const float a = ok ? sgn * nu : 0.0f, b = ok ? sgn * nv : 0.0f;
+    const float margin = 2e-5f * mag * scale;                                   // >> the rounding of the plane evaluations
+    const float c = ok ? -(a * hu + b * hv) - margin : -1.0f;                   // unusable: never separates (value -1, far margin 3e38)
+    const float ax = proj == 1 ? 0.0f : a, ay = proj == 0 ? 0.0f : (proj == 1 ? a : b), az = proj == 2 ? 0.0f : b;
+    SL.r[0] = fmaxf(ax, 0.0f); SL.r[1] = fminf(ax, 0.0f); SL.r[2] = fmaxf(ay, 0.0f); SL.r[3] = fminf(ay, 0.0f);
+    SL.r[4] = fmaxf(az, 0.0f); SL.r[5] = fminf(az, 0.0f); SL.r[6] = c; SL.r[7] = ok ? 2.0f * margin : 3e38f;
+    if (tk == 6) {          // near box: AABB of hull(S, h)
+        SL.r[0] = fminf(slx, hx); SL.r[1] = fminf(sly, hy); SL.r[2] = fminf(slz, hz);
+        SL.r[3] = fmaxf(shx, hx); SL.r[4] = fmaxf(shy, hy); SL.r[5] = fmaxf(shz, hz);
+    }
+    if (tk == 7) {          // far box: AABB of the far cone { h + tau * (h - s) : s in S, tau >= 0 }
+        SL.r[0] = hx >= shx ? hx : -3e38f; SL.r[1] = hy >= shy ? hy : -3e38f; SL.r[2] = hz >= shz ? hz : -3e38f;
+        SL.r[3] = hx <= slx ? hx : 3e38f; SL.r[4] = hy <= sly ? hy : 3e38f; SL.r[5] = hz <= slz ? hz : 3e38f;
+    }
+    return SL;
+}
+
+// this lane's test on a padded box: near = the box is outside the near shaft by this test, far = outside the far cone by this test.
+// NaN anywhere compares false = keep.
+__device__ __forceinline__ void shaft_lane_test(const ShaftLanes &SL, const int tk, const float lx, const float ly, const float lz, const float hx, const float hy,
+                                                const float hz, bool &near_out, bool &far_out) {
+    const float mn = __builtin_fmaf(SL.r[0], lx, __builtin_fmaf(SL.r[1], hx, __builtin_fmaf(SL.r[2], ly, __builtin_fmaf(SL.r[3], hy,
+                     __builtin_fmaf(SL.r[4], lz, __builtin_fmaf(SL.r[5], hz, SL.r[6]))))));
+    const float mx = __builtin_fmaf(SL.r[0], hx, __builtin_fmaf(SL.r[1], lx, __builtin_fmaf(SL.r[2], hy, __builtin_fmaf(SL.r[3], ly,
+                     __builtin_fmaf(SL.r[4], hz, __builtin_fmaf(SL.r[5], lz, SL.r[6]))))));
+    const bool box_out = (lx > SL.r[3]) || (hx < SL.r[0]) || (ly > SL.r[4]) || (hy < SL.r[1]) || (lz > SL.r[5]) || (hz < SL.r[2]);
+    near_out = tk < 6 ? (mn > 0.0f) : (tk == 6 && box_out);
+    far_out = tk < 6 ? (mx + SL.r[7] < 0.0f) : (tk == 7 && box_out);
+}
+// byte j of a 64-bit ballot, for lane j < 8: does any of the 8 tests of child / chunk j say "outside"?
+__device__ __forceinline__ bool ballot_byte_any(const unsigned long long b, const int lane) {
+    return ((b >> ((lane & 7) * 8)) & 0xffull) != 0ull;
+}
+
+#define RT_LEAF_SLOTS 16
+#define RT_COST_TRI_STEP 58u
+
+// One leaf of the shaft walk.  Chunk bounds are shaft-tested 8 at a time (lane = (chunk, test)); what survives goes through the per-ray
+// chunk test (lane = ray) and the triangle tests (lane = triangle); the next chunk's records are loaded while the current one is processed.
+// where a shaft walk hands big leaves to (the leaf-task queue of the k_shadow<.., CONT> launch that follows): budget 0 = never
+struct ShaftTasks {
+    ContTask *tasks;
+    uint32_t *count;
+    uint32_t cap, budget, target, unit;
+};
+
+__device__ __forceinline__ void shaft_leaf(const uint32_t ni, const uint32_t first, const uint32_t cnt, const uint32_t chunk0, const TriRec *__restrict__ tris,
+                                           const ChunkBound *__restrict__ chunks, const int lane, const RayLane &R, const ShaftLanes &SL, const ShaftTasks &TQ,
+                                           unsigned long long live, bool &occluded) {
+    const float ox = R.ox, oy = R.oy, oz = R.oz, dx = R.dx, dy = R.dy, dz = R.dz;
+    const TriRec *__restrict__ T = tris + first;
+    bool mine = ((live >> lane) & 1ull) != 0ull;
+    auto test_lane = [&](const TriRec &tr) {
+        // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 (lanes = rays)
+        const float dn = dot3(dx, dy, dz, tr.nx, tr.ny, tr.nz);
+        const float t = (tr.nA - dot3(ox, oy, oz, tr.nx, tr.ny, tr.nz)) / dn;
+        const float v2x = (ox + t * dx) - tr.ax, v2y = (oy + t * dy) - tr.ay, v2z = (oz + t * dz) - tr.az;
+        const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
+        const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
+        const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
+        const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
+        const bool ok = mine && !(tr.flags & 1u) && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f);
+        occluded = occluded || (ok && t < 0.98f);
+    };
+    if (cnt <= RT_SCALAR_LEAF_MAX && static_cast<uint32_t>(__popcll(live)) * RT_COST_TRI_STEP > cnt * RT_COST_RAY_MODE) {
+        // small leaf, many rays: every lane steps through the wave-uniform records (scalar loads)
+        uint32_t k = 0;
+        for (; k + 1u < cnt; k += 2u) {
+            TriRec ta, tb;
+            tri_load_uniform2(T + k, ta, tb);
+            test_lane(ta);
+            test_lane(tb);
+        }
+        if (k < cnt) test_lane(tri_load_uniform(T + k));
+        return;
+    }
+    const uint32_t nchunk = (cnt + 63u) >> 6;
+    const ChunkBound *__restrict__ cbounds = chunks + chunk0;
+    const int tk = lane & 7, tc = lane >> 3;
+    unsigned long long occ_new = 0ull;
+    uint32_t c_first = 0u;
+    // A big leaf with many live rays is not ground through by this wave (one unit crossing a 979-triangle leaf with 64 rays is ~60k
+    // instructions: the tail of the whole launch): it becomes chunk-range tasks for the leaf-task launch, which merges its occluded
+    // bits into `vis` with atomicAnd.  Estimate as leaf_visit: a third of the chunks survive the per-ray test.
+    if (TQ.budget != 0u) {
+        const uint32_t est = nchunk * RT_COST_CHUNK_TEST + static_cast<uint32_t>(__popcll(live)) * ((nchunk + 2u) / 3u) * RT_COST_TRI_STEP;
+        if (est > TQ.budget) {
+            uint32_t ntask = (est + TQ.target - 1u) / TQ.target;
+            if (ntask > nchunk) ntask = nchunk;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(TQ.count, ntask);
+            base = uniform_u32(base);
+            // the counter only grows (the consumer clamps it): pieces past the end of the queue are processed here
+            const uint32_t fit = base >= TQ.cap ? 0u : (ntask < TQ.cap - base ? ntask : TQ.cap - base);
+            for (uint32_t i = static_cast<uint32_t>(lane); i < fit; i += 64u) {
+                ContTask t;
+                t.unit = TQ.unit; t.node = ni; t.mask = live;
+                t.c_begin = static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * i / ntask);
+                t.c_end = static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * (i + 1u) / ntask);
+                t.pad0 = t.pad1 = 0u;
+                TQ.tasks[base + i] = t;
+            }
+            if (fit == ntask) return;
+            c_first = static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * fit / ntask);     // (queue full) the rest of the leaf, inline
+        }
+    }
+    for (uint32_t cb0 = c_first & ~7u; cb0 < nchunk && live != 0ull; cb0 += 8u) {
+        const uint32_t myc = cb0 + static_cast<uint32_t>(tc);
+        const ChunkBound bd = cbounds[myc < nchunk ? myc : cb0];
+        bool near_out, far_out;
+        shaft_lane_test(SL, tk, bd.lo[0] - SL.pad, bd.lo[1] - SL.pad, bd.lo[2] - SL.pad, bd.hi[0] + SL.pad, bd.hi[1] + SL.pad, bd.hi[2] + SL.pad, near_out, far_out);
+        const unsigned long long b_out = __ballot(near_out && bd.never < 1.5f);
+        const uint32_t nhere = nchunk - cb0 < 8u ? nchunk - cb0 : 8u;
+        unsigned long long cm = __ballot(static_cast<uint32_t>(lane) < nhere && cb0 + static_cast<uint32_t>(lane) >= c_first && !ballot_byte_any(b_out, lane));      // bit j: chunk cb0 + j survives
+        RT_PROF_ADD(lane, 92, 1); RT_PROF_ADD(lane, 93, nhere); RT_PROF_ADD(lane, 94, __popcll(cm));
+        // next chunk of `cm` that some live ray cannot skip (per-ray conservative test, lanes = rays), or -1
+        auto find_next = [&](unsigned long long &todo_out) -> int {
+            while (cm != 0ull) {
+                const int j = static_cast<int>(__builtin_ctzll(cm));
+                cm &= cm - 1ull;
+                unsigned long long todo = live;
+                if (lane_f(bd.never, 8 * j) < 1.5f) {
+                    const float l0 = lane_f(bd.lo[0], 8 * j), l1 = lane_f(bd.lo[1], 8 * j), l2 = lane_f(bd.lo[2], 8 * j);
+                    const float h0 = lane_f(bd.hi[0], 8 * j), h1 = lane_f(bd.hi[1], 8 * j), h2 = lane_f(bd.hi[2], 8 * j);
+                    const float t0x = (l0 - R.slab_pad - ox) * R.idx, t1x = (h0 + R.slab_pad - ox) * R.idx;
+                    const float t0y = (l1 - R.slab_pad - oy) * R.idy, t1y = (h1 + R.slab_pad - oy) * R.idy;
+                    const float t0z = (l2 - R.slab_pad - oz) * R.idz, t1z = (h2 + R.slab_pad - oz) * R.idz;
+                    const float tin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+                    const float tout = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+                    const bool miss = (tin > tout) || (tout < -1e-3f) || (tin > 0.981f);
+                    todo = live & ~__ballot(miss);
+                }
+                if (todo != 0ull) { RT_PROF_ADD(lane, 95, 1); todo_out = todo; return j; }
+            }
+            return -1;
+        };
+        auto load_chunk = [&](const int j) -> TriRec {
+            const uint32_t k = (cb0 + static_cast<uint32_t>(j)) * 64u + static_cast<uint32_t>(lane);
+            return T[k < cnt ? k : 0u];
+        };
+        unsigned long long todo_cur = 0ull, todo_nxt = 0ull;
+        int cur = find_next(todo_cur);
+        if (cur < 0) continue;
+        TriRec tr = load_chunk(cur);
+        while (cur >= 0) {
+            const int nxt_j = find_next(todo_nxt);
+            TriRec nxt = tr;
+            if (nxt_j >= 0) nxt = load_chunk(nxt_j);
+            const uint32_t c0 = (cb0 + static_cast<uint32_t>(cur)) * 64u;
+            const uint32_t n = cnt - c0 < 64u ? cnt - c0 : 64u;
+            const bool hast = static_cast<uint32_t>(lane) < n && !(tr.flags & 1u);
+            unsigned long long todo = todo_cur & live;
+            while (todo != 0ull) {
+                const int r0 = static_cast<int>(__builtin_ctzll(todo));
+                todo &= todo - 1ull;
+                const bool two = todo != 0ull;
+                const int r1 = two ? static_cast<int>(__builtin_ctzll(todo)) : r0;
+                if (two) todo &= todo - 1ull;
+                float tq[2]; bool inq[2];
+                RT_PROF_ADD(lane, 2, two ? 2 : 1);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 (lanes = triangles, the ray broadcast)
+                    const int r = q == 0 ? r0 : r1;
+                    const float rdx = lane_f(dx, r), rdy = lane_f(dy, r), rdz = lane_f(dz, r);
+                    const float rox = lane_f(ox, r), roy = lane_f(oy, r), roz = lane_f(oz, r);
+                    const float dn = dot3(rdx, rdy, rdz, tr.nx, tr.ny, tr.nz);
+                    const float t = (tr.nA - dot3(rox, roy, roz, tr.nx, tr.ny, tr.nz)) / dn;
+                    const float v2x = (rox + t * rdx) - tr.ax, v2y = (roy + t * rdy) - tr.ay, v2z = (roz + t * rdz) - tr.az;
+                    const float d02 = dot3(tr.e0x, tr.e0y, tr.e0z, v2x, v2y, v2z);
+                    const float d12 = dot3(tr.e1x, tr.e1y, tr.e1z, v2x, v2y, v2z);
+                    const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
+                    const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
+                    tq[q] = t;
+                    inq[q] = hast && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f);
+                }
+                if (!two) inq[1] = false;
+                if (__ballot(inq[0] && tq[0] < 0.98f) != 0ull) { occ_new |= 1ull << r0; live &= ~(1ull << r0); }
+                if (__ballot(inq[1] && tq[1] < 0.98f) != 0ull) { occ_new |= 1ull << r1; live &= ~(1ull << r1); }
+            }
+            if (live == 0ull) break;
+            cur = nxt_j; tr = nxt; todo_cur = todo_nxt;
+        }
+    }
+    occluded = occluded || (((occ_new >> lane) & 1ull) != 0ull);
+}
+
+struct ShaftLds {
+    const DNode *nodes;            // LDS copy of the first n_lds nodes (the top of the breadth-first array)
+    uint32_t n_lds;
+    uint32_t *lnode;               // per-wave leaf list (RT_LEAF_SLOTS)
+    unsigned long long *lmask;
+#ifdef RT_PROFILE
+    PhaseClock *pc;
+#endif
+};
+
+__device__ __forceinline__ DNode node_from_lane(const DNode &mine, const int j) {
+    DNode o;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o.bmin[k] = lane_f(mine.bmin[k], j); o.bmax[k] = lane_f(mine.bmax[k], j);
+        o.clo[k] = lane_f(mine.clo[k], j); o.chi[k] = lane_f(mine.chi[k], j);
+    }
+    o.first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine.first), j));
+    o.count_flags = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine.count_flags), j));
+    o.pad[0] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine.pad[0]), j));
+    o.pad[1] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine.pad[1]), j));
+    return o;
+}
+
+__device__ __forceinline__ void shaft_walk(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris, const ChunkBound *__restrict__ chunks,
+                                           const WaveStack stk, const ShaftLds sl, const int lane, const DNode &root, const bool in_root,
+                                           const RayLane &R, const float brx, const float bry, const float brz, const ShaftLanes &SL, const ShaftTasks &TQ, bool &occluded) {
+    const float ox = R.ox, oy = R.oy, oz = R.oz;
+    const unsigned long long m0 = __ballot(in_root);
+    if (m0 == 0ull) return;
+    const int tk = lane & 7, tc = lane >> 3;
+    int sp = 0, nleaf = 0;
+    if (root.count_flags & RT_NODE_LEAF) {
+        if (lane == 0) { sl.lnode[0] = 0u; sl.lmask[0] = m0; }
+        nleaf = 1;
+    } else {
+        // stack entry = one GROUP: the children [first, first + cnt) of an inner node whose box the rays in `mask` hit
+        if (lane == 0) { stk.node[0] = root.first | ((root.count_flags & 0xfu) << 28); stk.mask[0] = m0; }
+        sp = 1;
+    }
+    while (sp > 0 || nleaf > 0) {
+        if (sp == 0 || nleaf > RT_LEAF_SLOTS - 8) {
+            // the leaves found so far (ONE inlined copy of the leaf code: all of them are processed here)
+            RT_PH(sl, 3);
+            for (int k = 0; k < nleaf; ++k) {
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t li = uniform_u32(sl.lnode[k]);
+                unsigned long long lm = uniform_u64(sl.lmask[k]);
+                lm &= ~__ballot(occluded);
+                if (lm == 0ull) continue;
+                uint32_t lf, lc, l0;
+                if (li < sl.n_lds) { lf = sl.nodes[li].first; lc = sl.nodes[li].count_flags; l0 = sl.nodes[li].pad[0]; }
+                else { lf = nodes[li].first; lc = nodes[li].count_flags; l0 = nodes[li].pad[0]; }
+                shaft_leaf(li, uniform_u32(lf), uniform_u32(lc) & 0x7fffffffu, uniform_u32(l0), tris, chunks, lane, R, SL, TQ, lm, occluded);
+            }
+            nleaf = 0;
+            continue;
+        }
+        --sp;
+        RT_PH(sl, 1);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t ent = uniform_u32(stk.node[sp]);
+        unsigned long long gm = uniform_u64(stk.mask[sp]);
+        gm &= ~__ballot(occluded);
+        if (gm == 0ull) continue;
+        const uint32_t base = ent & 0x0fffffffu, gcnt = ent >> 28;
+        // lane = (child tc, test tk): the child's record, then this lane's separating test on its content box and on its own box
+        const uint32_t ci = base + (static_cast<uint32_t>(tc) < gcnt ? static_cast<uint32_t>(tc) : 0u);
+        DNode ch;
+        if (base + gcnt <= sl.n_lds) ch = sl.nodes[ci];
+        else ch = nodes[ci];
+        bool c_near, c_far, n_near, n_far;
+        shaft_lane_test(SL, tk, ch.clo[0] - SL.pad, ch.clo[1] - SL.pad, ch.clo[2] - SL.pad, ch.chi[0] + SL.pad, ch.chi[1] + SL.pad, ch.chi[2] + SL.pad, c_near, c_far);
+        shaft_lane_test(SL, tk, ch.bmin[0] - SL.pad, ch.bmin[1] - SL.pad, ch.bmin[2] - SL.pad, ch.bmax[0] + SL.pad, ch.bmax[1] + SL.pad, ch.bmax[2] + SL.pad, n_near, n_far);
+        const unsigned long long b_c = __ballot(c_near && ch.pad[1] == 0u), b_nn = __ballot(n_near), b_nf = __ballot(n_far);
+        const bool culled = (SL.node_ok && ballot_byte_any(b_nn, lane) && ballot_byte_any(b_nf, lane)) || ballot_byte_any(b_c, lane);
+        unsigned long long surv = __ballot(static_cast<uint32_t>(lane) < gcnt && !culled);       // bit j: child j survives
+        RT_PROF_ADD(lane, 88, 1); RT_PROF_ADD(lane, 89, gcnt); RT_PROF_ADD(lane, 90, __popcll(surv));
+        RT_PH(sl, 2);
+        while (surv != 0ull) {
+            const int j = static_cast<int>(__builtin_ctzll(surv));
+            surv &= surv - 1ull;
+            const DNode nd = node_from_lane(ch, 8 * j);
+            bool h = ((gm >> lane) & 1ull) != 0ull && !occluded;
+            if (nd.pad[1] == 0u) {   // per-ray content test (as packet_walk): no countable point of the segment inside the subtree's content box
+                const float t0x = (nd.clo[0] - R.slab_pad - ox) * R.idx, t1x = (nd.chi[0] + R.slab_pad - ox) * R.idx;
+                const float t0y = (nd.clo[1] - R.slab_pad - oy) * R.idy, t1y = (nd.chi[1] + R.slab_pad - oy) * R.idy;
+                const float t0z = (nd.clo[2] - R.slab_pad - oz) * R.idz, t1z = (nd.chi[2] + R.slab_pad - oz) * R.idz;
+                const float tin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+                const float tout = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+                const bool miss = (tin > tout) || (tout < -1e-3f) || (tin > 0.981f);
+                h = h && !miss;
+                if (__ballot(h) == 0ull) continue;
+            }
+            h = h && box_hit_verified(nd.bmin, ox, oy, oz, R.dx, R.dy, R.dz, brx, bry, brz);     // BoundingBox::boxIntersect, exact
+            const unsigned long long hm = __ballot(h);
+            if (hm == 0ull) continue;
+            RT_PROF_ADD(lane, 91, 1);
+            const uint32_t cj = base + static_cast<uint32_t>(j);
+            if (nd.count_flags & RT_NODE_LEAF) {
+                if ((nd.count_flags & 0x7fffffffu) == 0u) continue;
+                // (a group adds at most 8 leaves and the list is emptied when it reaches RT_LEAF_SLOTS - 8 entries before the next group)
+                if (lane == 0) { sl.lnode[nleaf] = cj; sl.lmask[nleaf] = hm; }
+                ++nleaf;
+            } else {
+                if ((nd.count_flags & 0xfu) == 0u) continue;              // a "lost" node: no children
+                if (lane == 0) { stk.node[sp] = nd.first | ((nd.count_flags & 0xfu) << 28); stk.mask[sp] = hm; }
+                ++sp;
+            }
+        }
+    }
+    RT_PH(sl, 0);
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -1194,11 +1578,11 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
                                                            const DScene S, const DLights L, const int level, const int ctr_slot,
                                                            const int lslots, const uint32_t item_cap, const ShadeItem *__restrict__ items,
                                                            Control *__restrict__ ctl, unsigned long long *vis, const TaskQueues Q) {
-    __shared__ uint4 s_stage[FLAT ? 1 : RT_WAVES * RT_STAGE_TRIS * 5];        // flat scenes need neither staging buffer nor stack
-    __shared__ unsigned long long s_mask[FLAT ? 1 : RT_WAVES * RT_STACK];
+    __shared__ uint4 s_stage[1];                                              // k_shadow never stages leaves in LDS (leaf_visit<.., STAGED = false>)
+    __shared__ unsigned long long s_mask[FLAT ? 1 : RT_WAVES * RT_STACK];     // flat scenes need no stack
     __shared__ uint32_t s_node[FLAT ? 1 : RT_WAVES * RT_STACK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const WaveStack stk{s_node + (FLAT ? 0 : wave * RT_STACK), s_mask + (FLAT ? 0 : wave * RT_STACK), s_stage + (FLAT ? 0 : wave * RT_STAGE_TRIS * 5)};
+    const WaveStack stk{s_node + (FLAT ? 0 : wave * RT_STACK), s_mask + (FLAT ? 0 : wave * RT_STACK), s_stage};
     const uint32_t N = static_cast<uint32_t>(L.n_samples);
     const uint32_t G = N <= 64u ? 64u / N : 1u;              // (hit,light) pairs per wave
     const uint32_t P = (N + 63u) / 64u;                       // 64-sample passes (= mask words) per pair
@@ -1239,9 +1623,10 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     uint32_t c_rays = 0, c_box = 0, c_ref = 0;
     ShardedQueue q;
     uint32_t n_work = 0;
+    ShardMap tmap{0u, 0u, 0u, 0u};
     if (CONT) {
-        n_work = ctl->n_tasks[level][Q.q_in];
-        if (n_work > Q.cap) n_work = Q.cap;
+        tmap = shard_map(ctl->n_task_sh[level], lane, Q.cap / RT_LIST_SHARDS, 1u, 1u);     // producers clamp to the per-shard capacity too
+        n_work = tmap.total;
         q.init_static(n_work, gridDim.x * RT_WAVES, uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave)), lane);
     } else {
         // N > 64: the passes of one (hit, light) pair are consecutive units and walk the same part of the tree -- hand them out two
@@ -1266,7 +1651,9 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
         wc.pc = &pclk;
 #endif
         if (CONT) {
-            const ContTask task = Q.tasks_in[work];
+            uint32_t tsh, tloc, tn;
+            shard_find(tmap, work, tsh, tloc, tn);
+            const ContTask task = Q.tasks_in[tsh * (Q.cap / RT_LIST_SHARDS) + tloc];
             unit = uniform_u32(task.unit);
             wc.resume = true;
             wc.start_node = uniform_u32(task.node);
@@ -1277,7 +1664,8 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
         // leaf tasks only pay when the launch has few units per wave (dodge at 1080p: 41, +5 %); with thousands of units per
         // wave the dynamic queue balances on its own and the second pass is pure overhead (cfg4: 3,600 per wave, 58 vs 46 ms)
         if (!FLAT && Q.tasks_out != nullptr && Q.budget != 0u && units < 256ull * gridDim.x * RT_WAVES) {
-            wc.budget = Q.budget; wc.unit = unit; wc.tasks = Q.tasks_out; wc.task_count = &ctl->n_tasks[level][Q.q_out]; wc.task_cap = Q.cap;
+            const uint32_t tsh = blockIdx.x & (RT_LIST_SHARDS - 1u), tcap = Q.cap / RT_LIST_SHARDS;      // sharded task queue (Control::n_task_sh)
+            wc.budget = Q.budget; wc.unit = unit; wc.tasks = Q.tasks_out + tsh * tcap; wc.task_count = &ctl->n_task_sh[level][tsh * 16u]; wc.task_cap = tcap;
             wc.target = Q.target ? Q.target : Q.budget;
         }
         uint32_t g, s, pass = 0;
@@ -1347,7 +1735,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
 #ifdef RT_PROFILE
         pclk.to(0);
 #endif
-        walk<true, COUNT, FLAT>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, wc, plane, sroot, sx, sy, sz, ddx, ddy, ddz, ddx, ddy, ddz, srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref);
+        walk<true, COUNT, FLAT, false>(root, nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, wc, plane, sroot, sx, sy, sz, ddx, ddy, ddz, ddx, ddy, ddz, srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref);
 #ifdef RT_PROFILE
         pclk.to(7);
 #endif
@@ -1390,6 +1778,160 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
             if (c_ref) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_LEAF_TRI_REFS_SHADOW], static_cast<unsigned long long>(c_ref));
         }
     }
+}
+
+// ======================================================================================================
+// K2 on TREE scenes with one (hit, light) pair -- or one 64-sample pass of it -- per wave (N >= 33 samples): the shaft walk.
+// Same units, same queue and same output words as k_shadow<false, false, false>.
+// ======================================================================================================
+__global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(RT_SHADOW_WPE, 8)))
+void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris, const ChunkBound *__restrict__ chunks,
+                    const DScene S, const DLights L, const int level, const int ctr_slot, const int lslots, const uint32_t item_cap,
+                    const ShadeItem *__restrict__ items, Control *__restrict__ ctl, unsigned long long *__restrict__ vis, const TaskQueues Q) {
+    __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
+    __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
+    __shared__ uint4 s_top[RT_LDS_NODES * 4];                      // the top of the octree: first RT_LDS_NODES DNodes (breadth-first order)
+    __shared__ unsigned long long s_lmask[RT_WAVES * RT_LEAF_SLOTS];
+    __shared__ uint32_t s_lnode[RT_WAVES * RT_LEAF_SLOTS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, nullptr};
+    const uint32_t n_lds = S.n_nodes < RT_LDS_NODES ? S.n_nodes : RT_LDS_NODES;
+    {
+        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(nodes);
+        for (uint32_t i = threadIdx.x; i < n_lds * 4u; i += blockDim.x) s_top[i] = src[i];
+        __syncthreads();
+    }
+    ShaftLds sl{reinterpret_cast<const DNode *>(s_top), n_lds, s_lnode + wave * RT_LEAF_SLOTS, s_lmask + wave * RT_LEAF_SLOTS
+#ifdef RT_PROFILE
+                , nullptr
+#endif
+    };
+    const uint32_t N = static_cast<uint32_t>(L.n_samples);
+    const uint32_t P = (N + 63u) / 64u;                       // 64-sample passes (= mask words) per pair
+    const ShardMap imap = shard_map(ctl->n_items[level], lane, item_cap, static_cast<uint32_t>(lslots) * P, 1u);
+    const uint32_t units = imap.total;
+    const DNode root = nodes[0];
+    const uint32_t vst = static_cast<uint32_t>(L.vsteps > 0 ? L.vsteps : 1);
+    const bool blocks = sample_blocks(L);
+    const float fi_last = static_cast<float>(L.usteps - 1) + 0.5f, fj_last = static_cast<float>(L.vsteps - 1) + 0.5f;
+    // Everything that depends on the light alone is evaluated once for scene light 0 (one light, item sees the scene lights: every
+    // level-0 item); the lane's grid coordinates inside a pass are lane constants; the two run-time divisions of a unit (pair / pass,
+    // block row / column) go through a float reciprocal with an exact correction step instead of the ~30-instruction integer division.
+    const LightGrid lg0 = light_grid(L, L.pos[0][0], L.pos[0][1], L.pos[0][2]);
+    const uint32_t bpr = blocks ? (vst >> 3) : 1u;
+    const float inv_P = 1.0f / static_cast<float>(P), inv_bpr = 1.0f / static_cast<float>(bpr), inv_ls = 1.0f / static_cast<float>(lslots);
+    auto udiv = [](const uint32_t n, const uint32_t d, const float inv) -> uint32_t {
+        uint32_t qv = static_cast<uint32_t>(static_cast<float>(n) * inv);          // within +-2 of n / d for n < 2^31
+        if (qv * d > n) qv -= 1u;
+        if (qv * d > n) qv -= 1u;
+        if (n - qv * d >= d) qv += 1u;
+        if (n - qv * d >= d) qv += 1u;
+        return qv;
+    };
+    const float fi_lane = blocks ? static_cast<float>(static_cast<uint32_t>(lane) >> 3) : static_cast<float>(static_cast<uint32_t>(lane) / vst);
+    const float fj_lane = blocks ? static_cast<float>(static_cast<uint32_t>(lane) & 7u) : static_cast<float>(static_cast<uint32_t>(lane) % vst);
+    uint32_t c_rays = 0;
+    ShardedQueue q;
+    q.init(ctl->queue[ctr_slot], units, gridDim.x * RT_WAVES, blockIdx.x, lane, S.queue_local >= 0 ? static_cast<uint32_t>(S.queue_local) : (P > 1u ? 2u : 0u),
+           static_cast<uint32_t>(S.queue_div));
+#ifdef RT_PROFILE
+    PhaseClock pclk; pclk.start();
+    sl.pc = &pclk;
+    const unsigned long long wave_t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
+    if (lane == 0 && g_prof) atomicMin(&g_prof[100], wave_t0 + 1ull);           // (memset 0 = unset: see the host side)
+#endif
+    for (uint32_t unit = 0; q.next(unit);) {
+#ifdef RT_PROFILE
+        pclk.to(6);
+        const unsigned long long unit_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        uint32_t sh, lu, n_sh;
+        shard_find(imap, unit, sh, lu, n_sh);
+        const uint32_t g = P == 1u ? lu : udiv(lu, P, inv_P), pass = lu - g * P;                       // (hit, light) pair of the list shard, pass of it
+        const uint32_t item_i = lslots == 1 ? g : udiv(g, static_cast<uint32_t>(lslots), inv_ls);
+        const int l = static_cast<int>(g - item_i * static_cast<uint32_t>(lslots));
+        const ShadeItem it = items[uniform_u32(sh * item_cap + item_i)];      // wave-uniform: a scalar load
+        uint32_t s = pass * 64u + static_cast<uint32_t>(lane);
+        float fi = fi_lane + 0.5f, fj = fj_lane + 0.5f;                       // the lane's sample (i + 0.5, j + 0.5) -- P == 1: s = lane
+        float b_i0 = 0.5f, b_j0 = 0.5f, b_i1 = fi_last, b_j1 = fj_last;      // grid corners of the unit's samples (the whole light unless in blocks)
+        if (blocks) {
+            const uint32_t bi = udiv(pass, bpr, inv_bpr), bj = pass - bi * bpr;
+            s = (bi * 8u + (static_cast<uint32_t>(lane) >> 3)) * vst + bj * 8u + (static_cast<uint32_t>(lane) & 7u);
+            b_i0 = static_cast<float>(bi * 8u) + 0.5f; b_j0 = static_cast<float>(bj * 8u) + 0.5f;
+            b_i1 = static_cast<float>(bi * 8u + 7u) + 0.5f; b_j1 = static_cast<float>(bj * 8u + 7u) + 0.5f;
+            fi = (static_cast<float>(bi * 8u) + fi_lane) + 0.5f; fj = (static_cast<float>(bj * 8u) + fj_lane) + 0.5f;     // exact small integers
+        } else if (P > 1u) {
+            fi = static_cast<float>(s / vst) + 0.5f; fj = static_cast<float>(s % vst) + 0.5f;
+        }
+        const int nl = it.lmode ? 1 : L.n_lights;
+        const bool valid = s < N && l < nl;
+        const float hx = it.ox + it.t * it.dx, hy = it.oy + it.t * it.dy, hz = it.oz + it.t * it.dz;
+        LightGrid lg = lg0;
+        if (it.lmode != 0u || l != 0) {
+            const float px = it.lmode ? it.lx : L.pos[l][0], py = it.lmode ? it.ly : L.pos[l][1], pz = it.lmode ? it.lz : L.pos[l][2];
+            lg = light_grid(L, px, py, pz);
+        }
+        float sx, sy, sz, x0, y0, z0, x1, y1, z1;
+        grid_sample(lg, fi, fj, sx, sy, sz);
+        grid_sample(lg, b_i0, b_j0, x0, y0, z0);             // the samples are monotone in each grid index: two corners give the exact box
+        grid_sample(lg, b_i1, b_j1, x1, y1, z1);
+        const float ddx = hx - sx, ddy = hy - sy, ddz = hz - sz;
+        const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
+        const unsigned long long vis_index = (static_cast<unsigned long long>(g) + static_cast<unsigned long long>(sh) * item_cap * static_cast<unsigned long long>(lslots)) * P + pass;
+        c_rays += valid ? 1u : 0u;
+        const bool sroot = valid && box_hit_verified(root.bmin, sx, sy, sz, ddx, ddy, ddz, srx, sry, srz);
+        ShaftLanes SL = make_shaft_lanes(lane, hx, hy, hz, fminf(x0, x1), fminf(y0, y1), fminf(z0, z1), fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1), S.extent);
+        SL.node_ok = __ballot(valid && !(fabsf(ddx) > 0.0f && fabsf(ddy) > 0.0f && fabsf(ddz) > 0.0f && fabsf(ddx) + fabsf(ddy) + fabsf(ddz) < 3e38f)) == 0ull;
+        const RayLane R{sx, sy, sz, ddx, ddy, ddz, srx, sry, srz, 4e-4f * (fabsf(sx) + fabsf(sy) + fabsf(sz) + S.extent)};
+        bool occ = false;
+#ifdef RT_PROFILE
+        pclk.to(0);
+#endif
+        // leaf tasks only pay when the launch has few units per wave (k_shadow has the numbers)
+        const bool tasks_on = Q.tasks_out != nullptr && Q.budget != 0u && units < 256u * gridDim.x * RT_WAVES;
+        const uint32_t tsh = blockIdx.x & (RT_LIST_SHARDS - 1u), tcap = Q.cap / RT_LIST_SHARDS;          // sharded task queue (Control::n_task_sh)
+        const ShaftTasks TQ{Q.tasks_out + tsh * tcap, &ctl->n_task_sh[level][tsh * 16u], tcap, tasks_on ? Q.budget : 0u, Q.target ? Q.target : Q.budget, unit};
+        shaft_walk(nodes, tris, chunks, stk, sl, lane, root, sroot, R, srx, sry, srz, SL, TQ, occ);
+#ifdef RT_PROFILE
+        pclk.to(7);
+#endif
+        const unsigned long long vm = __ballot(valid && !occ);
+        if (lane == 0) vis[vis_index] = vm;
+#ifdef RT_PROFILE
+        if (lane == 0 && g_prof) {      // per-unit duration histogram: prof[560 + log2(10 ns ticks)], max prof[559]
+            const unsigned long long tu = __builtin_amdgcn_s_memrealtime();
+            const unsigned long long dtu = tu - unit_t0;
+            int b = 63 - __builtin_clzll(dtu | 1ull); if (b > 30) b = 30;
+            atomicAdd(&g_prof[560 + b], 1ull);
+            atomicMax(&g_prof[559], dtu);
+        }
+#endif
+    }
+#ifdef RT_PROFILE
+    pclk.flush(lane, 72);
+    const uint32_t c_rays_dbg = wave_sum(c_rays);
+    if (lane == 0 && g_prof) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        atomicMax(&g_prof[101], t1);
+        atomicAdd(&g_prof[102], t1 - wave_t0);
+        atomicAdd(&g_prof[103], 1ull);
+        const unsigned long long ref = g_prof[104];        // launch reference written by the first wave that ends (approximate origin)
+        if (ref == 0ull) atomicCAS(&g_prof[104], 0ull, wave_t0);
+        const unsigned long long org = g_prof[104] ? g_prof[104] : wave_t0;
+        unsigned long long bin = (t1 > org ? t1 - org : 0ull) / 5000ull;   // 50 us bins
+        if (bin > 39ull) bin = 39ull;
+        atomicAdd(&g_prof[110 + bin], 1ull);
+        unsigned long long sbin = (wave_t0 > org ? wave_t0 - org : 0ull) / 5000ull;
+        if (sbin > 39ull) sbin = 39ull;
+        atomicAdd(&g_prof[520 + sbin], 1ull);
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        atomicAdd(&g_prof[160 + (xcc & 7u) * 40u + bin], 1ull);
+        atomicAdd(&g_prof[500 + (xcc & 7u)], static_cast<unsigned long long>(c_rays_dbg));
+    }
+#endif
+    c_rays = wave_sum(c_rays);
+    if (lane == 0 && c_rays) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_SAMPLE], static_cast<unsigned long long>(c_rays));
 }
 
 // ======================================================================================================
@@ -1677,6 +2219,8 @@ void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow
         *trace_primary = q(k_stage<true, false, 0, false>, RT_WAVES * 64, 4);
         *trace_rays = q(k_stage<false, false, 0, false>, RT_WAVES * 64, 4);
         *shadow = q(k_shadow<false, false, false>, RT_WAVES * 64, 4);
+        const int shaft = q(k_shadow_shaft, RT_WAVES * 64, 4);
+        if (shaft < *shadow) *shadow = shaft;
     }
     *shade = q(k_shade, 256, 2);
 }
@@ -1731,6 +2275,12 @@ void launch_shadow(bool count, bool flat, int grid, hipStream_t st, const DScene
     const TaskQueues Q{nullptr, (flat || count) ? nullptr : tasks_out, 0u, 2u, cap, (flat || count) ? 0u : budget, target};
     if (count) { if (flat) RT_LAUNCH_SHADOW(true, true, false); else RT_LAUNCH_SHADOW(true, false, false); }
     else { if (flat) RT_LAUNCH_SHADOW(false, true, false); else RT_LAUNCH_SHADOW(false, false, false); }
+}
+
+void launch_shadow_shaft(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots, uint32_t item_cap,
+                         const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target) {
+    const TaskQueues Q{nullptr, tasks_out, 0u, 2u, cap, budget, target};
+    hipLaunchKernelGGL(k_shadow_shaft, dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S, L, level, slot, lslots, item_cap, items, ctl, vis, Q);
 }
 
 // processes the leaf tasks of queue q_in (leaf tasks never create new tasks)
