@@ -171,6 +171,18 @@ rt_status rt_trace_rays(rt_ctx *ctx, const rt_lights *lights, int32_t max_depth,
 /* replaces: Flyscene::lightStrikes (flyscene.cpp:912-954): n segments light[i] -> hit[i]; vis[i] = 1 iff visible   */
 rt_status rt_light_strikes(rt_ctx *ctx, int32_t n, const float *hit, const float *light, uint8_t *vis);
 
+/* ---- unit-parity entry points: the device functions of the path on caller-given inputs ------------------------------------------
+ * replaces: BoundingBox::boxIntersect (src/boundingBox.cpp:48-83) -- n boxes [n*6: min, max], segments origin/dest [n*3]; hit[i] = the
+ *           decision of the kernels' slab test (approximate-then-verify form, bit-identical to the reference by construction)       */
+rt_status rt_box_intersect(rt_ctx *ctx, int32_t n, const float *boxes, const float *origin, const float *dest, uint8_t *hit);
+/* replaces: BoxTree::intersect (src/boxTree.cpp:150-173) on the uploaded tree, reference semantics (no culling, no early-out): per ray
+ *           the number of boxIntersect calls, the sum of faces.size() over the intersected non-empty leaves, and a signature of that
+ *           leaf set: sum over its leaves of (index into rt_scene.nodes) * 2654435761 mod 2^32                                    */
+rt_status rt_tree_probe(rt_ctx *ctx, int32_t n, const float *origin, const float *dest, uint32_t *box_tests, uint32_t *leaf_refs, uint32_t *leaf_sig);
+/* replaces: Camera::screenToWorld (camera.hpp:155-173) for every pixel, evaluated by the device's primary-ray generator:
+ *           out[(j*W + i)*3 ..] = screenToWorld(Vector2f(i, j))                                                                   */
+rt_status rt_primary_points(rt_ctx *ctx, const rt_camera *cam, int32_t width, int32_t height, float *out);
+
 /* ---- host-side scene preparation (GL-free restatement of the Tucano loader + BoxTree builder) --------------- */
 typedef struct rt_host_scene rt_host_scene;
 /* replaces: MeshImporter::loadObjFile + mesh.normalizeModelMatrix() + BoxTree(mesh, capacity)

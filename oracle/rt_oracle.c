@@ -381,10 +381,24 @@ static int plane_box_overlap(const float normal[3], const float vert[3], const f
     return 0;
 }
 
-static int classify_face(const oscene *s, const float bmin[3], const float bmax[3], int face) {
+/* the six axisTest* members (boxTree.cpp:368-456): p = projection of the two given vertices on the axis, rad = box extent on it.
+   X01 / X02: p = a*v.y - b*v.z, rad = fa*bh.y + fb*bh.z;  Y02 / Y1: p = -a*v.x + b*v.z, rad = fa*bh.x + fb*bh.z;
+   Z12 / Z0:  p = a*v.x - b*v.y, rad = fa*bh.x + fb*bh.y  (Z12 takes std::max(p1, p2), the others std::max(p1, p0)) */
+static int ax_x(float a, float b, float fa, float fb, const float v0[3], const float v1[3], const float bh[3]) {
+    return axis_test(a * v0[1] - b * v0[2], a * v1[1] - b * v1[2], fa * bh[1] + fb * bh[2]);
+}
+static int ax_y(float a, float b, float fa, float fb, const float v0[3], const float v1[3], const float bh[3]) {
+    return axis_test(-a * v0[0] + b * v0[2], -a * v1[0] + b * v1[2], fa * bh[0] + fb * bh[2]);
+}
+static int ax_z12(float a, float b, float fa, float fb, const float v1[3], const float v2[3], const float bh[3]) {
+    return axis_test_z12(a * v1[0] - b * v1[1], a * v2[0] - b * v2[1], fa * bh[0] + fb * bh[1]);
+}
+static int ax_z0(float a, float b, float fa, float fb, const float v0[3], const float v1[3], const float bh[3]) {
+    return axis_test(a * v0[0] - b * v0[1], a * v1[0] - b * v1[1], fa * bh[0] + fb * bh[1]);
+}
+
+static int classify_tri(const float bmin[3], const float bmax[3], const float *V[3]) {
     /* BoxTree::clasifyFace, boxTree.cpp:203-336 */
-    const float *V[3];
-    for (int k = 0; k < 3; k++) V[k] = &s->wverts[s->face_vid[face * 3 + k] * 3];
     int count = 0;
     for (int k = 0; k < 3; k++) {
         const float *v = V[k];
@@ -404,26 +418,19 @@ static int classify_face(const oscene *s, const float bmin[3], const float bmax[
     float fex, fey, fez;
 
     fex = fabsf(e0[0]); fey = fabsf(e0[1]); fez = fabsf(e0[2]);
-    /* axisTestX01(e0.z, e0.y, fez, fey, a, c): p = a*v.y - b*v.z ; rad = fa*bh.y + fb*bh.z */
-    if (!axis_test(e0[2] * a[1] - e0[1] * a[2], e0[2] * c[1] - e0[1] * c[2], fez * bh[1] + fey * bh[2])) return 0;
-    /* axisTestY02(e0.z, e0.x, fez, fex, a, c): p = -a*v.x + b*v.z ; rad = fa*bh.x + fb*bh.z */
-    if (!axis_test(-e0[2] * a[0] + e0[0] * a[2], -e0[2] * c[0] + e0[0] * c[2], fez * bh[0] + fex * bh[2])) return 0;
-    /* axisTestZ12(e0.y, e0.x, fey, fex, b, c): p = a*v.x - b*v.y ; rad = fa*bh.x + fb*bh.y */
-    if (!axis_test_z12(e0[1] * b[0] - e0[0] * b[1], e0[1] * c[0] - e0[0] * c[1], fey * bh[0] + fex * bh[1])) return 0;
+    if (!ax_x(e0[2], e0[1], fez, fey, a, c, bh)) return 0;        /* axisTestX01(e0.z, e0.y, fez, fey, a, c) */
+    if (!ax_y(e0[2], e0[0], fez, fex, a, c, bh)) return 0;        /* axisTestY02(e0.z, e0.x, fez, fex, a, c) */
+    if (!ax_z12(e0[1], e0[0], fey, fex, b, c, bh)) return 0;      /* axisTestZ12(e0.y, e0.x, fey, fex, b, c) */
 
     fex = fabsf(e1[0]); fey = fabsf(e1[1]); fez = fabsf(e1[2]);
-    if (!axis_test(e1[2] * a[1] - e1[1] * a[2], e1[2] * c[1] - e1[1] * c[2], fez * bh[1] + fey * bh[2])) return 0;     /* X01(a,c) */
-    if (!axis_test(-e1[2] * a[0] + e1[0] * a[2], -e1[2] * c[0] + e1[0] * c[2], fez * bh[0] + fex * bh[2])) return 0;   /* Y02(a,c) */
-    /* axisTestZ0(e1.y, e1.x, fey, fex, a, b) */
-    if (!axis_test(e1[1] * a[0] - e1[0] * a[1], e1[1] * b[0] - e1[0] * b[1], fey * bh[0] + fex * bh[1])) return 0;
+    if (!ax_x(e1[2], e1[1], fez, fey, a, c, bh)) return 0;        /* X01(a,c) */
+    if (!ax_y(e1[2], e1[0], fez, fex, a, c, bh)) return 0;        /* Y02(a,c) */
+    if (!ax_z0(e1[1], e1[0], fey, fex, a, b, bh)) return 0;       /* axisTestZ0(e1.y, e1.x, fey, fex, a, b) */
 
     fex = fabsf(e2[0]); fey = fabsf(e2[1]); fez = fabsf(e2[2]);
-    /* axisTestX02(e2.z, e2.y, fez, fey, a, b) */
-    if (!axis_test(e2[2] * a[1] - e2[1] * a[2], e2[2] * b[1] - e2[1] * b[2], fez * bh[1] + fey * bh[2])) return 0;
-    /* axisTestY1(e2.z, e2.x, fez, fex, a, b) */
-    if (!axis_test(-e2[2] * a[0] + e2[0] * a[2], -e2[2] * b[0] + e2[0] * b[2], fez * bh[0] + fex * bh[2])) return 0;
-    /* axisTestZ12(e2.y, e2.x, fey, fex, b, c) */
-    if (!axis_test_z12(e2[1] * b[0] - e2[0] * b[1], e2[1] * c[0] - e2[0] * c[1], fey * bh[0] + fex * bh[1])) return 0;
+    if (!ax_x(e2[2], e2[1], fez, fey, a, b, bh)) return 0;        /* axisTestX02(e2.z, e2.y, fez, fey, a, b) */
+    if (!ax_y(e2[2], e2[0], fez, fex, a, b, bh)) return 0;        /* axisTestY1(e2.z, e2.x, fez, fex, a, b) */
+    if (!ax_z12(e2[1], e2[0], fey, fex, b, c, bh)) return 0;      /* axisTestZ12(e2.y, e2.x, fey, fex, b, c) */
 
     for (int k = 0; k < 3; k++) { /* findMinMax per axis, :302-322 */
         float mn = stdminf(stdminf(a[k], b[k]), c[k]);
@@ -435,6 +442,32 @@ static int classify_face(const oscene *s, const float bmin[3], const float bmax[
     cross3(ed1, ed2, nrm); normalize3_fixed(nrm);
     if (!plane_box_overlap(nrm, a, bh)) return 0;
     return 1;
+}
+
+static int classify_face(const oscene *s, const float bmin[3], const float bmax[3], int face) {
+    const float *V[3];
+    for (int k = 0; k < 3; k++) V[k] = &s->wverts[s->face_vid[face * 3 + k] * 3];
+    return classify_tri(bmin, bmax, V);
+}
+
+/* unit-parity entry points for the reference pins (tests/test_ref_pins.py) */
+int orc_classify_tri(const float bmin[3], const float bmax[3], const float tri[9]) {
+    const float *V[3] = {tri, tri + 3, tri + 6};
+    return classify_tri(bmin, bmax, V);
+}
+void orc_sat_prims(const float in[16], unsigned char dec[8], float mm[2]) {
+    /* in: a b fa fb | v0 | v1 | boxhalfsize | 3 spare -- the same call pattern as oracle/ref_probe2.cpp `prim` */
+    const float *v0 = in + 4, *v1 = in + 7, *bh = in + 10;
+    dec[0] = (unsigned char)ax_x(in[0], in[1], in[2], in[3], v0, v1, bh);      /* axisTestX01 */
+    dec[1] = (unsigned char)ax_y(in[0], in[1], in[2], in[3], v0, v1, bh);      /* axisTestY02 */
+    dec[2] = (unsigned char)ax_z12(in[0], in[1], in[2], in[3], v0, v1, bh);    /* axisTestZ12 */
+    dec[3] = (unsigned char)ax_z0(in[0], in[1], in[2], in[3], v0, v1, bh);     /* axisTestZ0 */
+    dec[4] = (unsigned char)ax_x(in[0], in[1], in[2], in[3], v0, v1, bh);      /* axisTestX02 */
+    dec[5] = (unsigned char)ax_y(in[0], in[1], in[2], in[3], v0, v1, bh);      /* axisTestY1 */
+    dec[6] = (unsigned char)plane_box_overlap(v0, v1, bh);
+    dec[7] = (unsigned char)plane_box_overlap(v1, v0, bh);
+    mm[0] = stdminf(stdminf(in[13], in[14]), in[15]);                          /* findMinMax, boxTree.cpp:338-343 */
+    mm[1] = stdmaxf(stdmaxf(in[13], in[14]), in[15]);
 }
 
 static void node_split(oscene *s, int ni, int depth) {
@@ -559,6 +592,31 @@ int orc_tree_intersect(const oscene *s, const float o[3], const float dest[3], i
     int total = sc.nlist;
     scratch_free(&sc);
     return total;
+}
+
+/* the intersected non-empty leaves themselves (node indices, ascending): the same walk as tree_collect.  Pinned against the
+   reference's BoxTree::intersect run on a tree whose leaves carry their own index as the only "face" (oracle/ref_probe2.cpp). */
+int orc_tree_leaves(const oscene *s, const float o[3], const float dest[3], int *out_nodes, int cap) {
+    int *queue = malloc(sizeof(int) * (size_t)(s->nnodes + 1));
+    int qh = 0, qt = 0, n_out = 0;
+    queue[qt++] = 0;
+    while (qh < qt) {
+        const int ni = queue[qh++];
+        const onode *n = &s->nodes[ni];
+        if (!orc_box_intersect(n->bmin, n->bmax, o, dest)) continue;
+        if (n->is_leaf && !n->is_empty) {
+            if (n->nfaces > 0) { if (n_out < cap) out_nodes[n_out] = ni; n_out++; }
+        } else if (!n->is_empty) {
+            for (int c = 0; c < n->nchildren; c++) {
+                const onode *ch = &s->nodes[n->child[c]];
+                if (ch->is_empty) continue;
+                if (orc_box_intersect(ch->bmin, ch->bmax, o, dest)) queue[qt++] = n->child[c];
+            }
+        }
+    }
+    free(queue);
+    qsort(out_nodes, (size_t)(n_out < cap ? n_out : cap), sizeof(int), cmp_int);
+    return n_out;
 }
 
 /* ------------------------------------------------------------------ */
@@ -831,26 +889,61 @@ void orc_default_camera(ocamera *c, int w, int h) {
     c->center[0] = 0.0f; c->center[1] = 0.0f; c->center[2] = 2.0f;
 }
 
+/* Eigen 3.3.7 pieces that Flycamera::updateViewMatrix / Camera::getCenter / screenToWorld evaluate (vendored source):
+   AngleAxis::toRotationMatrix (Geometry/AngleAxis.h), 3x3 inverse by cofactors (LU/InverseImpl.h:126-170), Affine inverse
+   (Geometry/Transform.h: linear().inverse(), translation = -linear_inv * translation).  Pinned bit for bit by
+   tests/test_ref_pins.py against the reference's Camera compiled in place (oracle/ref_probe2.cpp). */
+static void eig_angle_axis(float angle, const float ax[3], float R[9]) {
+    float s = sinf(angle), c = cosf(angle);
+    float sa[3] = {s * ax[0], s * ax[1], s * ax[2]};
+    float c1 = 1.0f - c;
+    float ca[3] = {c1 * ax[0], c1 * ax[1], c1 * ax[2]};
+    float tmp;
+    tmp = ca[0] * ax[1]; R[0 * 3 + 1] = tmp - sa[2]; R[1 * 3 + 0] = tmp + sa[2];
+    tmp = ca[0] * ax[2]; R[0 * 3 + 2] = tmp + sa[1]; R[2 * 3 + 0] = tmp - sa[1];
+    tmp = ca[1] * ax[2]; R[1 * 3 + 2] = tmp - sa[0]; R[2 * 3 + 1] = tmp + sa[0];
+    R[0] = ca[0] * ax[0] + c; R[4] = ca[1] * ax[1] + c; R[8] = ca[2] * ax[2] + c;
+}
+static void eig_mat3_vec(const float M[9], const float v[3], float o[3]) {
+    for (int r = 0; r < 3; r++) o[r] = M[r * 3] * v[0] + (M[r * 3 + 1] * v[1] + M[r * 3 + 2] * v[2]);
+}
+static float eig_cof(const float m[9], int i, int j) {
+    int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return m[i1 * 3 + j1] * m[i2 * 3 + j2] - m[i1 * 3 + j2] * m[i2 * 3 + j1];
+}
+static void eig_mat3_inverse(const float m[9], float inv[9]) {
+    float c0 = eig_cof(m, 0, 0), c1 = eig_cof(m, 1, 0), c2 = eig_cof(m, 2, 0);
+    float det = c0 * m[0] + (c1 * m[3] + c2 * m[6]);
+    float invdet = 1.0f / det;
+    inv[0] = c0 * invdet; inv[1] = c1 * invdet; inv[2] = c2 * invdet;
+    inv[3] = eig_cof(m, 0, 1) * invdet; inv[4] = eig_cof(m, 1, 1) * invdet; inv[5] = eig_cof(m, 2, 1) * invdet;
+    inv[6] = eig_cof(m, 0, 2) * invdet; inv[7] = eig_cof(m, 1, 2) * invdet; inv[8] = eig_cof(m, 2, 2) * invdet;
+}
+
 void orc_yaw_camera(ocamera *c, int w, int h, float yaw) {
-    /* EXTENSION (animation, cfg5): rotation_Y_axis = yaw, rotation_X_axis = 0 in Flycamera::updateViewMatrix
-       (flycamera.hpp:166-191).  view.linear = R with rows rotX,rotY,rotZ; view.translation = R*(0,0,-2).
-       R is orthonormal up to rounding; inverse linear is taken as R^T evaluated in float, centre = -R^T t.
-       No reference output exists for yaw != 0: parity unpinned. */
+    /* Flycamera::updateViewMatrix with rotation_Y_axis = yaw, rotation_X_axis = 0 (flycamera.hpp:166-191), then
+       Camera::getCenter (camera.hpp:115-118) and getViewMatrix().inverse() (camera.hpp:170). */
     orc_default_camera(c, w, h);
     if (yaw == 0.0f) return;
-    float cs = cosf(yaw), sn = sinf(yaw);
-    float rx[3] = {cs, 0.0f, -sn};  /* AngleAxis(yaw, Y) * UnitX */
-    float rz[3] = {sn, 0.0f, cs};   /* AngleAxis(yaw, Y) * UnitZ */
-    float ry[3] = {0.0f, 1.0f, 0.0f};
-    normalize3_fixed(rx); normalize3_fixed(rz);
-    float R[9] = {rx[0], rx[1], rx[2], ry[0], ry[1], ry[2], rz[0], rz[1], rz[2]};
-    float t[3]; float dt[3] = {0.0f, 0.0f, -2.0f};
-    for (int r = 0; r < 3; r++) t[r] = (R[r * 3] * dt[0] + R[r * 3 + 1] * dt[1]) + R[r * 3 + 2] * dt[2];
+    const float uy[3] = {0.0f, 1.0f, 0.0f}, ux[3] = {1.0f, 0.0f, 0.0f}, uz[3] = {0.0f, 0.0f, 1.0f};
+    float Ry[9], R0[9], rx[3], ry[3], rz[3], tmpv[3];
+    eig_angle_axis(yaw, uy, Ry);
+    eig_mat3_vec(Ry, ux, rx); normalize3_fixed(rx);
+    eig_mat3_vec(Ry, uz, tmpv);
+    eig_angle_axis(0.0f, rx, R0);
+    eig_mat3_vec(R0, tmpv, rz); normalize3_fixed(rz);
+    eig_mat3_vec(R0, uy, ry); normalize3_fixed(ry);
+    float R[9] = {rx[0], rx[1], rx[2], ry[0], ry[1], ry[2], rz[0], rz[1], rz[2]};   /* rotation_matrix rows; view.linear = I * I * R */
+    float dt[3] = {0.0f, 0.0f, -2.0f}, t[3];
+    eig_mat3_vec(R, dt, t);                                                          /* translate(default_translation) */
+    float Linv[9];
+    eig_mat3_inverse(R, Linv);
     for (int r = 0; r < 3; r++) {
-        for (int k = 0; k < 3; k++) c->inv_view[r * 4 + k] = R[k * 3 + r];
-        float v = (R[0 * 3 + r] * t[0] + R[1 * 3 + r] * t[1]) + R[2 * 3 + r] * t[2];
-        c->inv_view[r * 4 + 3] = -v;
-        c->center[r] = -v;
+        for (int k = 0; k < 3; k++) c->inv_view[r * 4 + k] = Linv[r * 3 + k];
+        /* translation of the inverse: (-Linv) * t ; centre: Linv * (-t) -- the same values */
+        float v = (-Linv[r * 3]) * t[0] + ((-Linv[r * 3 + 1]) * t[1] + (-Linv[r * 3 + 2]) * t[2]);
+        c->inv_view[r * 4 + 3] = v;
+        c->center[r] = Linv[r * 3] * (-t[0]) + (Linv[r * 3 + 1] * (-t[1]) + Linv[r * 3 + 2] * (-t[2]));
     }
 }
 

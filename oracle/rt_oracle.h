@@ -117,7 +117,10 @@ void orc_default_lights(olights *l, int area);               /* flyscene.cpp:68,
 /* ---- per-function entry points (unit parity) ---- */
 int   orc_box_intersect(const float bmin[3], const float bmax[3], const float o[3], const float dest[3]); /* boundingBox.cpp:48-83 */
 float orc_ray_triangle(const oscene *s, const float o[3], const float d[3], int face);                   /* flyscene.cpp:787-819 */
+int   orc_classify_tri(const float bmin[3], const float bmax[3], const float tri[9]);                   /* boxTree.cpp:203-336 (clasifyFace) */
+void  orc_sat_prims(const float in[16], unsigned char dec[8], float mm[2]);                              /* boxTree.cpp:338-456 */
 int   orc_tree_intersect(const oscene *s, const float o[3], const float dest[3], int *out_faces, int cap, ostats *st); /* boxTree.cpp:150-173 */
+int   orc_tree_leaves(const oscene *s, const float o[3], const float dest[3], int *out_nodes, int cap);  /* boxTree.cpp:150-173: the leaves */
 int   orc_closest_hit(const oscene *s, const float o[3], const float d[3], float *t_out, ostats *st);    /* flyscene.cpp:655-691 */
 int   orc_light_samples(const olights *l, const float p[3], float *out_xyz /* [n*3] */);                 /* flyscene.cpp:962-972, arealight.hpp:15-25 */
 int   orc_light_strikes(const oscene *s, const float hit[3], const float *pts, int n, unsigned char *vis, ostats *st, int is_sample); /* flyscene.cpp:912-954 */

@@ -88,6 +88,9 @@ _SIGNATURES = [
     ("rt_trace_rays", C.c_int, [C.c_void_p, _P(rt_lights), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),
     ("rt_light_strikes", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("rt_box_intersect", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("rt_tree_probe", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("rt_primary_points", C.c_int, [C.c_void_p, _P(rt_camera), C.c_int32, C.c_int32, C.c_void_p]),
     ("rt_host_scene_load", C.c_int, [C.c_char_p, C.c_int32, C.c_int32, _P(C.c_void_p)]),
     ("rt_host_scene_free", None, [C.c_void_p]),
     ("rt_host_scene_view", C.c_int, [C.c_void_p, _P(rt_scene)]),

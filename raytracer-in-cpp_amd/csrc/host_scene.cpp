@@ -496,22 +496,60 @@ void default_camera(rt_camera *cam, int w, int h) {
     cam->center[2] = 2.0f;
 }
 
+// The fly camera's view for camera paths: Flycamera::updateViewMatrix with rotation_Y_axis = yaw, rotation_X_axis = 0
+// (flycamera.hpp:166-191), Camera::getCenter (camera.hpp:115-118) and getViewMatrix().inverse() (camera.hpp:170), evaluated with the
+// operation order of the vendored Eigen 3.3.7: AngleAxis::toRotationMatrix (Geometry/AngleAxis.h), the 3x3 inverse by cofactors
+// (LU/InverseImpl.h:126-170) and the affine inverse (Geometry/Transform.h: translation = -linear_inv * translation).
+namespace {
+void angle_axis_matrix(float angle, const float ax[3], float R[9]) {
+    const float s = std::sin(angle), c = std::cos(angle);
+    const float sa[3] = {s * ax[0], s * ax[1], s * ax[2]};
+    const float c1 = 1.0f - c;
+    const float ca[3] = {c1 * ax[0], c1 * ax[1], c1 * ax[2]};
+    float tmp;
+    tmp = ca[0] * ax[1]; R[1] = tmp - sa[2]; R[3] = tmp + sa[2];
+    tmp = ca[0] * ax[2]; R[2] = tmp + sa[1]; R[6] = tmp - sa[1];
+    tmp = ca[1] * ax[2]; R[5] = tmp - sa[0]; R[7] = tmp + sa[0];
+    R[0] = ca[0] * ax[0] + c; R[4] = ca[1] * ax[1] + c; R[8] = ca[2] * ax[2] + c;
+}
+void mat3_vec(const float M[9], const float v[3], float o[3]) {
+    for (int r = 0; r < 3; ++r) o[r] = M[r * 3] * v[0] + (M[r * 3 + 1] * v[1] + M[r * 3 + 2] * v[2]);
+}
+float cofactor3(const float m[9], int i, int j) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return m[i1 * 3 + j1] * m[i2 * 3 + j2] - m[i1 * 3 + j2] * m[i2 * 3 + j1];
+}
+void mat3_inverse(const float m[9], float inv[9]) {
+    const float c0 = cofactor3(m, 0, 0), c1 = cofactor3(m, 1, 0), c2 = cofactor3(m, 2, 0);
+    const float det = c0 * m[0] + (c1 * m[3] + c2 * m[6]);
+    const float invdet = 1.0f / det;
+    inv[0] = c0 * invdet; inv[1] = c1 * invdet; inv[2] = c2 * invdet;
+    inv[3] = cofactor3(m, 0, 1) * invdet; inv[4] = cofactor3(m, 1, 1) * invdet; inv[5] = cofactor3(m, 2, 1) * invdet;
+    inv[6] = cofactor3(m, 0, 2) * invdet; inv[7] = cofactor3(m, 1, 2) * invdet; inv[8] = cofactor3(m, 2, 2) * invdet;
+}
+void unit3(float v[3]) { const V3 u = unit_fixed({v[0], v[1], v[2]}); v[0] = u.x; v[1] = u.y; v[2] = u.z; }
+}  // namespace
+
 void yaw_camera(rt_camera *cam, int w, int h, float yaw) {
-    // EXTENSION for camera paths: Flycamera::updateViewMatrix with rotation_Y_axis = yaw, rotation_X_axis = 0
-    // (flycamera.hpp:166-191).  The view's linear part R has rows rotX, rotY, rotZ; its inverse is taken as R^T.
     default_camera(cam, w, h);
     if (yaw == 0.0f) return;
-    const float cs = std::cos(yaw), sn = std::sin(yaw);
-    const V3 rx = unit_fixed({cs, 0.f, -sn}), ry{0.f, 1.f, 0.f}, rz = unit_fixed({sn, 0.f, cs});
-    const float R[9] = {rx.x, rx.y, rx.z, ry.x, ry.y, ry.z, rz.x, rz.y, rz.z};
+    const float uy[3] = {0.f, 1.f, 0.f}, ux[3] = {1.f, 0.f, 0.f}, uz[3] = {0.f, 0.f, 1.f};
+    float Ry[9], R0[9], rx[3], ry[3], rz[3], tmpv[3];
+    angle_axis_matrix(yaw, uy, Ry);
+    mat3_vec(Ry, ux, rx); unit3(rx);
+    mat3_vec(Ry, uz, tmpv);
+    angle_axis_matrix(0.0f, rx, R0);
+    mat3_vec(R0, tmpv, rz); unit3(rz);
+    mat3_vec(R0, uy, ry); unit3(ry);
+    const float R[9] = {rx[0], rx[1], rx[2], ry[0], ry[1], ry[2], rz[0], rz[1], rz[2]};      // rotation_matrix rows; view.linear = I * I * R
     const float push[3] = {0.f, 0.f, -2.f};
-    float t[3];
-    for (int r = 0; r < 3; ++r) t[r] = (R[r * 3] * push[0] + R[r * 3 + 1] * push[1]) + R[r * 3 + 2] * push[2];
+    float t[3], Linv[9];
+    mat3_vec(R, push, t);                                                                     // translate(default_translation)
+    mat3_inverse(R, Linv);
     for (int r = 0; r < 3; ++r) {
-        for (int k = 0; k < 3; ++k) cam->inv_view[r * 4 + k] = R[k * 3 + r];
-        const float v = (R[r] * t[0] + R[3 + r] * t[1]) + R[6 + r] * t[2];
-        cam->inv_view[r * 4 + 3] = -v;
-        cam->center[r] = -v;
+        for (int k = 0; k < 3; ++k) cam->inv_view[r * 4 + k] = Linv[r * 3 + k];
+        cam->inv_view[r * 4 + 3] = (-Linv[r * 3]) * t[0] + ((-Linv[r * 3 + 1]) * t[1] + (-Linv[r * 3 + 2]) * t[2]);
+        cam->center[r] = Linv[r * 3] * (-t[0]) + (Linv[r * 3 + 1] * (-t[1]) + Linv[r * 3 + 2] * (-t[2]));
     }
 }
 

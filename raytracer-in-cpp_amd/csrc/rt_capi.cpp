@@ -32,6 +32,9 @@ void launch_stage(bool primary, bool count, int stage, bool cont, int grid, hipS
                   const DFrame &Fr, int level, int lslots, const RayItem *rays_in, ShadeItem *items, Control *ctl, float4 *rec, int32_t *out_hit,
                   float *out_t, unsigned long long *best, unsigned long long *lit, const TaskQueues &Q);
 void launch_segments(int grid, hipStream_t st, const DScene &S, int n, const float *hit, const float *light, uint8_t *vis);
+void launch_box_probe(hipStream_t st, int n, const float *box, const float *org, const float *dst, uint8_t *out);
+void launch_tree_probe(int grid, hipStream_t st, const DScene &S, int n, const float *org, const float *dst, uint32_t *out_box, uint32_t *out_ref, uint32_t *out_sig);
+void launch_primary_probe(int grid, hipStream_t st, const DCam *cam, int W, int H, float *out);
 void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow, int *shade);
 void launch_set_prof(hipStream_t st, Control *ctl);
 }  // namespace rtamd
@@ -975,6 +978,70 @@ extern "C" rt_status rt_light_strikes(rt_ctx *c, int32_t n, const float *hit, co
     } while (0);
     (void)hipFree(d_hit); (void)hipFree(d_light); (void)hipFree(d_vis);
     return s;
+}
+
+// ---- unit-parity probes ---------------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {          // scoped device allocation for the probe entry points
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess; }
+};
+}  // namespace
+
+extern "C" rt_status rt_box_intersect(rt_ctx *c, int32_t n, const float *boxes, const float *origin, const float *dest, uint8_t *hit) {
+    if (!c) return RT_ERR_INVALID;
+    if (n < 0 || (n && (!boxes || !origin || !dest || !hit))) { c->err = "rt_box_intersect: bad arguments"; return RT_ERR_INVALID; }
+    if (n == 0) return RT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf b, o, d, h;
+    const size_t nn = static_cast<size_t>(n);
+    if (!b.alloc(nn * 24) || !o.alloc(nn * 12) || !d.alloc(nn * 12) || !h.alloc(nn)) { c->err = "rt_box_intersect: hipMalloc failed"; return RT_ERR_HIP; }
+    HIPCHK(c, hipMemcpy(b.p, boxes, nn * 24, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(o.p, origin, nn * 12, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d.p, dest, nn * 12, hipMemcpyHostToDevice));
+    launch_box_probe(c->stream, n, static_cast<const float *>(b.p), static_cast<const float *>(o.p), static_cast<const float *>(d.p), static_cast<uint8_t *>(h.p));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(hit, h.p, nn, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" rt_status rt_tree_probe(rt_ctx *c, int32_t n, const float *origin, const float *dest, uint32_t *box_tests, uint32_t *leaf_refs, uint32_t *leaf_sig) {
+    if (!c) return RT_ERR_INVALID;
+    if (!c->has_scene) { c->err = "rt_tree_probe before rt_upload_scene"; return RT_ERR_NO_SCENE; }
+    if (n < 0 || (n && (!origin || !dest || !box_tests || !leaf_refs || !leaf_sig))) { c->err = "rt_tree_probe: bad arguments"; return RT_ERR_INVALID; }
+    if (n == 0) return RT_OK;
+    if (c->flat) { c->err = "rt_tree_probe: the scene is a single leaf (no tree)"; return RT_ERR_UNSUPPORTED; }
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf o, d, ob, orf, os;
+    const size_t nn = static_cast<size_t>(n);
+    if (!o.alloc(nn * 12) || !d.alloc(nn * 12) || !ob.alloc(nn * 4) || !orf.alloc(nn * 4) || !os.alloc(nn * 4)) { c->err = "rt_tree_probe: hipMalloc failed"; return RT_ERR_HIP; }
+    HIPCHK(c, hipMemcpy(o.p, origin, nn * 12, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d.p, dest, nn * 12, hipMemcpyHostToDevice));
+    const int blocks = (n + 255) / 256;
+    launch_tree_probe(blocks < c->cus * 4 ? blocks : c->cus * 4, c->stream, c->S, n, static_cast<const float *>(o.p), static_cast<const float *>(d.p),
+                      static_cast<uint32_t *>(ob.p), static_cast<uint32_t *>(orf.p), static_cast<uint32_t *>(os.p));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(box_tests, ob.p, nn * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(leaf_refs, orf.p, nn * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(leaf_sig, os.p, nn * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" rt_status rt_primary_points(rt_ctx *c, const rt_camera *cam, int32_t w, int32_t h, float *out) {
+    if (!c) return RT_ERR_INVALID;
+    if (!cam || !out || w <= 0 || h <= 0) { c->err = "rt_primary_points: bad arguments"; return RT_ERR_INVALID; }
+    HIPCHK(c, hipSetDevice(c->device));
+    DCam dc;
+    make_cam(cam, &dc);
+    DevBuf dcam, dout;
+    const size_t nn = static_cast<size_t>(w) * static_cast<size_t>(h) * 3;
+    if (!dcam.alloc(sizeof(DCam)) || !dout.alloc(nn * 4)) { c->err = "rt_primary_points: hipMalloc failed"; return RT_ERR_HIP; }
+    HIPCHK(c, hipMemcpy(dcam.p, &dc, sizeof dc, hipMemcpyHostToDevice));
+    launch_primary_probe(c->cus * 4, c->stream, static_cast<const DCam *>(dcam.p), w, h, static_cast<float *>(dout.p));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dout.p, nn * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
 }
 
 // ---- host scene wrappers ------------------------------------------------------------------------------------

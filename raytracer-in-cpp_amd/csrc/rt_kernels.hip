@@ -386,11 +386,11 @@ template <bool ANY, bool COUNT, bool STAGED = true>
 __device__ __forceinline__ void leaf_visit(const DNode &nd, const uint32_t ni, const TriRec *__restrict__ tris, const ChunkBound *__restrict__ chunks,
                                            const uint32_t *__restrict__ leaf_chunk0, const WaveStack stk, const int lane, const WalkCtl &wc,
                                            const RayLane &R, unsigned long long live, bool mine,
-                                           float &best_t, int &best_f, bool &occluded, uint32_t &cnt_ref) {
+                                           float &best_t, int &best_f, bool &occluded, uint32_t &cnt_ref, uint32_t &cnt_sig) {
     const float ox = R.ox, oy = R.oy, oz = R.oz, dx = R.dx, dy = R.dy, dz = R.dz;
     const float idx_ = R.idx, idy_ = R.idy, idz_ = R.idz, slab_pad = R.slab_pad;
     const uint32_t cnt = nd.count_flags & 0x7fffffffu;
-    if (COUNT && mine) cnt_ref += cnt;
+    if (COUNT && mine) { cnt_ref += cnt; cnt_sig += ni * 2654435761u; }      // cnt_sig: signature of the ray's set of intersected leaves (rt_tree_probe)
     const TriRec *__restrict__ T = tris + nd.first;
     const uint32_t nchunk = (cnt + 63u) >> 6;
     // lanes=triangles estimate: one bound test per chunk + live rays x the share of chunks a ray cannot skip
@@ -598,7 +598,7 @@ __device__ __forceinline__ void packet_walk(const DNode *__restrict__ nodes, con
                                             const float bx, const float by, const float bz,      // box-test direction (dest - origin)
                                             const float brx, const float bry, const float brz,   // v_rcp_f32 of it (approximate)
                                             float &best_t, int &best_f, bool &occluded,
-                                            uint32_t &cnt_box, uint32_t &cnt_ref) {
+                                            uint32_t &cnt_box, uint32_t &cnt_ref, uint32_t &cnt_sig) {
     // The conservative box tests (content boxes of nodes, chunk boxes of big leaves) only ever SKIP work, so approximate
     // arithmetic is fine: they use the v_rcp_f32 reciprocals of the box-test direction that the caller already holds (it is the
     // triangle-test direction up to one rounding).  A zero component gives inf: an origin inside that slab yields (-inf, +inf) = no
@@ -629,7 +629,7 @@ __device__ __forceinline__ void packet_walk(const DNode *__restrict__ nodes, con
         const uint32_t cnt = nd.count_flags & 0x7fffffffu;
         if (nd.count_flags & RT_NODE_LEAF) {
             leaf_visit<ANY, COUNT, STAGED>(nd, ni, tris, chunks, leaf_chunk0, stk, lane, wc, RayLane{ox, oy, oz, dx, dy, dz, idx_, idy_, idz_, slab_pad}, live, mine,
-                                   best_t, best_f, occluded, cnt_ref);
+                                   best_t, best_f, occluded, cnt_ref, cnt_sig);
         } else {
             RT_TILE_COUNT(stk, lane, 3, cnt);
             RT_PH(wc, 2);
@@ -748,9 +748,10 @@ __device__ __forceinline__ void walk(const DNode &root, const DNode *__restrict_
                                      const float bx, const float by, const float bz,
                                      const float brx, const float bry, const float brz,
                                      float &best_t, int &best_f, bool &occluded, uint32_t &cnt_box, uint32_t &cnt_ref) {
+    uint32_t sig_unused = 0u;
     if (FLAT) flat_walk<ANY, COUNT>(root, tris, in_root, wc.seg, pl, ox, oy, oz, dx, dy, dz, best_t, best_f, occluded, cnt_box, cnt_ref);
     else packet_walk<ANY, COUNT, STAGED>(nodes, tris, chunks, leaf_chunk0, extent, stk, lane, wc, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz,
-                                 brx, bry, brz, best_t, best_f, occluded, cnt_box, cnt_ref);
+                                 brx, bry, brz, best_t, best_f, occluded, cnt_box, cnt_ref, sig_unused);
 }
 
 // ======================================================================================================
@@ -1200,6 +1201,21 @@ __device__ __forceinline__ void light_sample(const DLights &L, const float px, c
     light_sample_ij(L, px, py, pz, static_cast<float>(i) + 0.5f, static_cast<float>(j) + 0.5f, sx, sy, sz);
 }
 
+// Camera::screenToWorld (camera.hpp:155-173): raster -> [-1,1] in double, cast, perspective scale, inverse view.  One definition for
+// the fused k_trace, the staged k_stage and the probe kernel (rt_primary_points).
+__device__ __forceinline__ void screen_point(const DCam &cam, const int x, const int y, float &sx, float &sy, float &sz) {
+    const float fi = static_cast<float>(x), fj = static_cast<float>(y);
+    float n0 = static_cast<float>(2.0 * static_cast<double>(fi - cam.vp[0]) / static_cast<double>(cam.vp[2]) - 1.0);
+    float n1 = static_cast<float>(1.0 - 2.0 * static_cast<double>(fj - cam.vp[1]) / static_cast<double>(cam.vp[3]));
+    const float n2 = -1.0f;
+    n0 = n0 * cam.k0;
+    n1 = n1 * cam.k1;
+    const float *m = cam.inv_view;
+    sx = ((m[0] * n0 + m[1] * n1) + m[2] * n2) + m[3] * 1.0f;
+    sy = ((m[4] * n0 + m[5] * n1) + m[6] * n2) + m[7] * 1.0f;
+    sz = ((m[8] * n0 + m[9] * n1) + m[10] * n2) + m[11] * 1.0f;
+}
+
 // ======================================================================================================
 // K1: closest hit + light-centre visibility.  PRIMARY: fused primary-ray generation (Camera::screenToWorld)
 // and root-AABB cull of raytraceScene's serial loop (flyscene.cpp:573-598); otherwise reads compacted rays.
@@ -1244,17 +1260,8 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const DNode *__restrict
             valid = (x < F.width) && (lr < F.local_rows);
             const int y = F.row0 + ((lr / F.stripe) * F.nranks + F.rank) * F.stripe + (lr % F.stripe);
             pix = static_cast<uint32_t>(lr) * static_cast<uint32_t>(F.width) + static_cast<uint32_t>(x);
-            // Camera::screenToWorld, camera.hpp:155-173: raster -> [-1,1] in double, cast, perspective scale, inverse view
-            const float fi = static_cast<float>(x), fj = static_cast<float>(y);
-            float n0 = static_cast<float>(2.0 * static_cast<double>(fi - cam.vp[0]) / static_cast<double>(cam.vp[2]) - 1.0);
-            float n1 = static_cast<float>(1.0 - 2.0 * static_cast<double>(fj - cam.vp[1]) / static_cast<double>(cam.vp[3]));
-            const float n2 = -1.0f;
-            n0 = n0 * cam.k0;
-            n1 = n1 * cam.k1;
-            const float *m = cam.inv_view;
-            const float sx = ((m[0] * n0 + m[1] * n1) + m[2] * n2) + m[3] * 1.0f;
-            const float sy = ((m[4] * n0 + m[5] * n1) + m[6] * n2) + m[7] * 1.0f;
-            const float sz = ((m[8] * n0 + m[9] * n1) + m[10] * n2) + m[11] * 1.0f;
+            float sx, sy, sz;
+            screen_point(cam, x, y, sx, sy, sz);
             ox = cam.center[0]; oy = cam.center[1]; oz = cam.center[2];
             dx = sx - ox; dy = sy - oy; dz = sz - oz;          // direction = screen - origin (UNNORMALISED), flyscene.cpp:619
             const bool pre = valid && box_hit_verified(root.bmin, ox, oy, oz, dx, dy, dz, __builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz));   // flyscene.cpp:576
@@ -1380,17 +1387,8 @@ __device__ __forceinline__ TileRay tile_ray(const uint32_t tile, const int lane,
         r.valid = (x < F.width) && (lr < F.local_rows);
         const int y = F.row0 + ((lr / F.stripe) * F.nranks + F.rank) * F.stripe + (lr % F.stripe);
         r.pix = static_cast<uint32_t>(lr) * static_cast<uint32_t>(F.width) + static_cast<uint32_t>(x);
-        // Camera::screenToWorld, camera.hpp:155-173 (see k_trace)
-        const float fi = static_cast<float>(x), fj = static_cast<float>(y);
-        float n0 = static_cast<float>(2.0 * static_cast<double>(fi - cam.vp[0]) / static_cast<double>(cam.vp[2]) - 1.0);
-        float n1 = static_cast<float>(1.0 - 2.0 * static_cast<double>(fj - cam.vp[1]) / static_cast<double>(cam.vp[3]));
-        const float n2 = -1.0f;
-        n0 = n0 * cam.k0;
-        n1 = n1 * cam.k1;
-        const float *m = cam.inv_view;
-        const float sx = ((m[0] * n0 + m[1] * n1) + m[2] * n2) + m[3] * 1.0f;
-        const float sy = ((m[4] * n0 + m[5] * n1) + m[6] * n2) + m[7] * 1.0f;
-        const float sz = ((m[8] * n0 + m[9] * n1) + m[10] * n2) + m[11] * 1.0f;
+        float sx, sy, sz;
+        screen_point(cam, x, y, sx, sy, sz);
         r.ox = cam.center[0]; r.oy = cam.center[1]; r.oz = cam.center[2];
         r.dx = sx - r.ox; r.dy = sy - r.oy; r.dz = sz - r.oz;          // flyscene.cpp:619
         r.pre = r.valid && box_hit_verified(root.bmin, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, __builtin_amdgcn_rcpf(r.dx),
@@ -1474,8 +1472,9 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
             float best_t = 3.402823466e+38f;
             int best_f = -1;
             bool dummy = false;
+            uint32_t sig_unused = 0u;
             packet_walk<false, COUNT>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, wc, in_root, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz,
-                                      bx, by, bz, brx, bry, brz, best_t, best_f, dummy, c_box, c_ref);
+                                      bx, by, bz, brx, bry, brz, best_t, best_f, dummy, c_box, c_ref, sig_unused);
             const bool found = best_f >= 0 && static_cast<uint32_t>(best_f) < S.n_faces;
             const unsigned long long key = found ? ((static_cast<unsigned long long>(__float_as_uint(best_t)) << 32) | static_cast<uint32_t>(best_f))
                                                  : RT_NO_HIT_KEY;
@@ -1508,8 +1507,9 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
                 }
                 float t_unused = 0.f; int f_unused = -1;
                 bool occ = false;
+                uint32_t sig_unused = 0u;
                 packet_walk<true, COUNT>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, wc, sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz,
-                                         srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref);
+                                         srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref, sig_unused);
                 if (CONT) {
                     const unsigned long long om = __ballot(act && occ);
                     if (lane == 0 && om != 0ull) atomicAnd(&lit[lit_index], ~om);
@@ -2190,10 +2190,74 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_segments(const DNode *__restr
         const float ddx = hit[j * 3] - px, ddy = hit[j * 3 + 1] - py, ddz = hit[j * 3 + 2] - pz;
         const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
         const bool sroot = valid && box_hit_verified(root.bmin, px, py, pz, ddx, ddy, ddz, srx, sry, srz);
-        float t_unused = 0.f; int f_unused = -1; bool occ = false; uint32_t c0 = 0, c1 = 0;
-        packet_walk<true, false>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, walk_plain(), sroot, px, py, pz, ddx, ddy, ddz, ddx, ddy, ddz, srx, sry, srz, t_unused, f_unused, occ, c0, c1);
+        float t_unused = 0.f; int f_unused = -1; bool occ = false; uint32_t c0 = 0, c1 = 0, c2 = 0;
+        packet_walk<true, false>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, walk_plain(), sroot, px, py, pz, ddx, ddy, ddz, ddx, ddy, ddz, srx, sry, srz, t_unused, f_unused, occ, c0, c1, c2);
         if (valid) vis[i] = occ ? 0 : 1;
     }
+}
+
+// ======================================================================================================
+// Unit-parity probes (rt_box_intersect / rt_tree_probe / rt_primary_points): the PRODUCT's device functions on caller-given inputs,
+// so that tests can pin them directly to outputs of the reference's own boundingBox.cpp / boxTree.cpp / camera.hpp.
+// ======================================================================================================
+__global__ __launch_bounds__(256) void k_box_probe(const int n, const float *__restrict__ box, const float *__restrict__ org, const float *__restrict__ dst,
+                                                   uint8_t *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float b[6] = {box[i * 6], box[i * 6 + 1], box[i * 6 + 2], box[i * 6 + 3], box[i * 6 + 4], box[i * 6 + 5]};
+    const float ox = org[i * 3], oy = org[i * 3 + 1], oz = org[i * 3 + 2];
+    const float dx = dst[i * 3] - ox, dy = dst[i * 3 + 1] - oy, dz = dst[i * 3 + 2] - oz;        // Eigen: dir = dest - origin (boundingBox.cpp:51)
+    out[i] = box_hit_verified(b, ox, oy, oz, dx, dy, dz, __builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz)) ? 1 : 0;
+}
+
+// BoxTree::intersect (boxTree.cpp:150-173) as the traversal kernels perform it, reference semantics (COUNT variant: no early-out, no
+// culling): per ray the boxIntersect calls, the leaf face references and a signature of the set of intersected non-empty leaves
+// (sum of device node index x 2654435761 mod 2^32).
+__global__ __launch_bounds__(RT_WAVES * 64) void k_tree_probe(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris,
+                                                              const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
+                                                              const DScene S, const int n, const float *__restrict__ org, const float *__restrict__ dst,
+                                                              uint32_t *__restrict__ out_box, uint32_t *__restrict__ out_ref, uint32_t *__restrict__ out_sig) {
+    __shared__ uint4 s_stage[RT_WAVES * RT_STAGE_TRIS * 5];
+    __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
+    __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, s_stage + wave * RT_STAGE_TRIS * 5};
+    const DNode root = nodes[0];
+    const int waves_total = gridDim.x * RT_WAVES;
+    for (int base = (blockIdx.x * RT_WAVES + wave) * 64; base < n; base += waves_total * 64) {
+        const int i = base + lane;
+        const bool valid = i < n;
+        const int j = valid ? i : 0;
+        const float ox = org[j * 3], oy = org[j * 3 + 1], oz = org[j * 3 + 2];
+        const float dx = dst[j * 3] - ox, dy = dst[j * 3 + 1] - oy, dz = dst[j * 3 + 2] - oz;
+        const float rx = __builtin_amdgcn_rcpf(dx), ry = __builtin_amdgcn_rcpf(dy), rz = __builtin_amdgcn_rcpf(dz);
+        // BoxTree::intersect tests the root itself first (the callers' own pre-test of the root is theirs, not part of intersect)
+        const bool in_root = valid && box_hit_verified(root.bmin, ox, oy, oz, dx, dy, dz, rx, ry, rz);
+        float t_unused = 0.f; int f_unused = -1; bool occ = false; uint32_t c_box = 0, c_ref = 0, c_sig = 0;
+        packet_walk<true, true>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, walk_plain(), in_root, ox, oy, oz, dx, dy, dz, dx, dy, dz, rx, ry, rz,
+                                t_unused, f_unused, occ, c_box, c_ref, c_sig);
+        if (valid) { out_box[i] = c_box + (in_root ? 0u : 1u); out_ref[i] = c_ref; out_sig[i] = c_sig; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_primary_probe(const DCam *__restrict__ camp, const int W, const int H, float *__restrict__ out) {
+    const DCam cam = *camp;
+    const size_t total = static_cast<size_t>(W) * static_cast<size_t>(H);
+    for (size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < total; p += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        float sx, sy, sz;
+        screen_point(cam, static_cast<int>(p % static_cast<size_t>(W)), static_cast<int>(p / static_cast<size_t>(W)), sx, sy, sz);
+        out[p * 3] = sx; out[p * 3 + 1] = sy; out[p * 3 + 2] = sz;
+    }
+}
+
+void launch_box_probe(hipStream_t st, int n, const float *box, const float *org, const float *dst, uint8_t *out) {
+    hipLaunchKernelGGL(k_box_probe, dim3((n + 255) / 256), dim3(256), 0, st, n, box, org, dst, out);
+}
+void launch_tree_probe(int grid, hipStream_t st, const DScene &S, int n, const float *org, const float *dst, uint32_t *out_box, uint32_t *out_ref, uint32_t *out_sig) {
+    hipLaunchKernelGGL(k_tree_probe, dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, n, org, dst, out_box, out_ref, out_sig);
+}
+void launch_primary_probe(int grid, hipStream_t st, const DCam *cam, int W, int H, float *out) {
+    hipLaunchKernelGGL(k_primary_probe, dim3(grid), dim3(256), 0, st, cam, W, H, out);
 }
 
 #ifdef RT_PROFILE

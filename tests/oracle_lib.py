@@ -59,6 +59,11 @@ class Oracle:
         L.orc_ray_triangle.restype = C.c_float
         L.orc_tree_intersect.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int, C.POINTER(ostats)]
         L.orc_tree_intersect.restype = C.c_int
+        L.orc_tree_leaves.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]
+        L.orc_tree_leaves.restype = C.c_int
+        L.orc_classify_tri.argtypes = [C.POINTER(C.c_float)] * 3
+        L.orc_classify_tri.restype = C.c_int
+        L.orc_sat_prims.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_ubyte), C.POINTER(C.c_float)]
         L.orc_closest_hit.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(ostats)]
         L.orc_closest_hit.restype = C.c_int
         L.orc_light_samples.argtypes = [C.POINTER(olights), C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -220,6 +225,13 @@ class OracleScene:
         e = np.asarray(dest, np.float32)
         buf = (C.c_int * max(self.nfaces, 1))()
         n = self.lib.orc_tree_intersect(self.h, _f(o), _f(e), buf, self.nfaces, None)
+        return np.array(buf[:n], np.int32)
+
+    def tree_leaves(self, o, dest):
+        o = np.asarray(o, np.float32)
+        e = np.asarray(dest, np.float32)
+        buf = (C.c_int * max(self.nnodes, 1))()
+        n = self.lib.orc_tree_leaves(self.h, _f(o), _f(e), buf, self.nnodes)
         return np.array(buf[:n], np.int32)
 
     def light_strikes(self, hit, pts):
