@@ -538,6 +538,101 @@ void orc_build_tree(oscene *s, int capacity, int maxdepth) {
 }
 
 /* ------------------------------------------------------------------ */
+/* powf of phongShade (flyscene.cpp:852)                                */
+/* ------------------------------------------------------------------ */
+/* The reference calls libm's powf.  In glibc 2.35 (this image, and the one the reference outputs of SURVEY Appendix A were made
+   with) that is the ARM "optimized routines" powf (sysdeps/ieee754/flt-32/e_powf.c, POWF_LOG2_TABLE_BITS 4, EXP2F_TABLE_BITS 5,
+   no TOINT intrinsics) and on x86-64 CPUs with FMA+AVX2 the ifunc picks the build with fused multiply-adds.  Its published algorithm
+   is restated here with EXPLICIT fma() at exactly the places that build contracts (read off this image's libm.so.6), so that the
+   oracle no longer depends on which variant the host's ifunc picks and the device can mirror it bit for bit.
+   tests/test_powf.py pins orc_powf to the host's powf exhaustively over the ranges the shipped materials use. */
+static const struct { double invc, logc; } POWF_LOG2[16] = {
+    {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2}, {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},
+    {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2}, {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4}, {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5},
+    {0x1p+0, 0x0p+0}, {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4}, {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+    {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3}, {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2}, {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},
+    {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2}};
+static const double POWF_A[5] = {0x1.27616c9496e0bp-2, -0x1.71969a075c67ap-2, 0x1.ec70a6ca7baddp-2, -0x1.7154748bef6c8p-1, 0x1.71547652ab82bp+0};
+static const uint64_t POWF_EXP2[32] = {
+    0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51, 0x3fef72b83c7d517b, 0x3fef54873168b9aa, 0x3fef387a6e756238,
+    0x3fef1e9df51fdee1, 0x3fef06fe0a31b715, 0x3feef1a7373aa9cb, 0x3feedea64c123422, 0x3feece086061892d, 0x3feebfdad5362a27, 0x3feeb42b569d4f82,
+    0x3feeab07dd485429, 0x3feea47eb03a5585, 0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74, 0x3feea11473eb0187, 0x3feea589994cce13, 0x3feeace5422aa0db,
+    0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d, 0x3feee89f995ad3ad, 0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069,
+    0x3fef5818dcfba487, 0x3fef7c97337b9b5f, 0x3fefa4afa2a490da, 0x3fefd0765b6e4540};
+static const double POWF_C[3] = {0x1.c6af84b912394p-5, 0x1.ebfce50fac4f3p-3, 0x1.62e42ff0c52d6p-1};
+
+float orc_powf(float x, float y) {
+    uint32_t ix, iy;
+    memcpy(&ix, &x, 4); memcpy(&iy, &y, 4);
+    /* The fast path needs a positive normal or subnormal x and a finite non-zero y: everything phongShade can pass except y == 0,
+       x == 0, x == 1-with-special-y and non-finite values, which go to libm (identical in every variant: no arithmetic involved). */
+    if (!(ix - 0x00800000u < 0x7f800000u - 0x00800000u) || (2u * iy - 1u >= 2u * 0x7f800000u - 1u)) {
+        if (ix - 1u < 0x007fffffu && !(2u * iy - 1u >= 2u * 0x7f800000u - 1u)) {
+            /* subnormal x: normalise as e_powf.c does */
+            float xs = x * 0x1p23f;
+            memcpy(&ix, &xs, 4);
+            ix &= 0x7fffffffu;
+            ix -= 23u << 23;
+        } else {
+            return powf(x, y);
+        }
+    }
+    /* log2_inline */
+    uint32_t tmp = ix - 0x3f330000u;
+    int i = (int)((tmp >> 19) & 15u);
+    uint32_t top = tmp & 0xff800000u;
+    uint32_t iz = ix - top;
+    int k = (int32_t)top >> 23;
+    float zf; memcpy(&zf, &iz, 4);
+    double z = (double)zf;
+    double r = fma(z, POWF_LOG2[i].invc, -1.0);
+    double y0 = POWF_LOG2[i].logc + (double)k;
+    double r2 = r * r;
+    double yy = fma(POWF_A[0], r, POWF_A[1]);
+    double p = fma(POWF_A[2], r, POWF_A[3]);
+    double r4 = r2 * r2;
+    double q = fma(POWF_A[4], r, y0);
+    q = fma(p, r2, q);
+    double logx = fma(yy, r4, q);
+    double ylogx = (double)y * logx;
+    uint64_t u; memcpy(&u, &ylogx, 8);
+    if (((u >> 47) & 0xffffu) >= 0x80bfu) {            /* |y * log2(x)| >= 126 */
+        if (ylogx > 0x1.fffffffd1d571p+6) return powf(x, y);      /* overflow (and the rounding-mode check just below it): not reachable */
+        if (ylogx > 0x1.fffffffa3aae2p+6) return powf(x, y);      /* from phongShade (x <= 1 + ulp, y > 0); libm decides */
+        if (ylogx <= -150.0) return 0.0f;                          /* __math_uflowf(0): 0x1p-95f * 0x1p-95f */
+        if (ylogx < -149.0) return 0x1p-149f;                      /* __math_may_uflowf(0): 0x1.4p-75f * 0x1.4p-75f rounds to the smallest subnormal */
+    }
+    /* exp2_inline */
+    double kd = ylogx + 0x1.8p+47;
+    uint64_t ki; memcpy(&ki, &kd, 8);
+    kd -= 0x1.8p+47;
+    double rr = ylogx - kd;
+    uint64_t t = POWF_EXP2[ki & 31u];
+    t += ki << 47;
+    double sc; memcpy(&sc, &t, 8);
+    double zz = fma(POWF_C[0], rr, POWF_C[1]);
+    double rr2 = rr * rr;
+    double yv = fma(POWF_C[2], rr, 1.0);
+    yv = fma(zz, rr2, yv);
+    yv = yv * sc;
+    return (float)yv;
+}
+
+/* compares orc_powf with the host libm's powf for every float bit pattern in [lo_bits, hi_bits] (step `stride`); returns the number of
+   mismatching results and stores the first one */
+long orc_powf_compare(float expo, uint32_t lo_bits, uint32_t hi_bits, uint32_t stride, uint32_t *first_bad) {
+    long bad = 0;
+    for (uint64_t b = lo_bits; b <= hi_bits; b += stride) {
+        uint32_t bb = (uint32_t)b; float x; memcpy(&x, &bb, 4);
+        float a = orc_powf(x, expo), c = powf(x, expo);
+        uint32_t ua, uc; memcpy(&ua, &a, 4); memcpy(&uc, &c, 4);
+        if (ua != uc && !(a != a && c != c)) { if (!bad && first_bad) *first_bad = bb; bad++; }
+    }
+    return bad;
+}
+
+/* ------------------------------------------------------------------ */
 /* per-thread scratch for BoxTree::intersect's std::set<int>           */
 /* ------------------------------------------------------------------ */
 typedef struct {
@@ -774,7 +869,7 @@ static void phong(const oscene *s, const olights *L, const float origin[3], cons
             normalize3_fixed(eye);
             float mr[3] = {-1.0f * rl[0], -1.0f * rl[1], -1.0f * rl[2]};
             float cosphi = stdmaxf(0.0f, dot3(eye, mr));
-            float pw = powf(cosphi, m->shininess);
+            float pw = orc_powf(cosphi, m->shininess);     /* = libm powf (see orc_powf) */
             for (int k = 0; k < 3; k++) {
                 float diffuse = (L->color[k] * m->kd[k]) * costheta;
                 float specular = (L->color[k] * m->ks[k]) * pw;

@@ -127,6 +127,8 @@ int   orc_light_strikes(const oscene *s, const float hit[3], const float *pts, i
 void  orc_interp_normal(const oscene *s, const float p[3], int face, float out[3]);                      /* flyscene.cpp:864-888 */
 void  orc_phong(const oscene *s, const olights *l, const float origin[3], const float hit[3], int face,
                 const float *lightpts, int nl, float out[3], ostats *st);                                /* flyscene.cpp:822-859 */
+float orc_powf(float x, float y);                                                                        /* flyscene.cpp:852 powf = glibc 2.35 e_powf.c, FMA build */
+long  orc_powf_compare(float expo, uint32_t lo_bits, uint32_t hi_bits, uint32_t stride, uint32_t *first_bad);
 float orc_fresnel(const float I[3], const float N[3], float ior);                                        /* flyscene.cpp:890-910 */
 void  orc_trace_ray(const oscene *s, const olights *l, const float o[3], const float d[3], int level, int max_depth,
                     const float *lightpts, int nl, float out[3], ostats *st);                            /* flyscene.cpp:651-771 */

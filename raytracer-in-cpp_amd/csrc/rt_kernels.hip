@@ -22,7 +22,7 @@
 // Numerics: compiled with -ffp-contract=off and correctly rounded fp32 divide/sqrt; every expression keeps the
 // reference's operation order (Eigen 3.3.7: a.dot(b) = a0*b0 + (a1*b1 + a2*b2)), std::min/std::max are spelt as
 // the ternaries libstdc++ uses, so integer results (face ids, 8-bit pixels) are bit-exact and float RGB differs
-// from the CPU path only through powf (evaluated here in double precision and rounded once).
+// from the CPU path nowhere: powf is glibc's published algorithm evaluated bit for bit (pow_shininess).
 #include <hip/hip_runtime.h>
 
 #include "rt_device.hpp"
@@ -1938,23 +1938,82 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
 // K3: Phong shading of lit hits + material dispatch + bounce-ray emission with wave-level compaction.
 // phongShade flyscene.cpp:822-859, getInterpolatedNormal :864-888, fresnel :890-910, traceRay dispatch :712-760.
 // ======================================================================================================
-// powf(cosphi, Ns) of phongShade (flyscene.cpp:852).  The CPU path calls glibc's powf (<= 0.52 ulp).  Here the power is
-// evaluated in DOUBLE and rounded to float once (= correctly rounded float except ~1e-7 of inputs): exponents that are
-// non-negative integers -- every shipped .mtl: 10, 324, 500, 225 -- by binary exponentiation (<= 20 DP multiplies, relative
-// error < 3e-15), anything else through pow(double, double).
-__device__ __forceinline__ float pow_shininess(float base, float expo) {
-    const float fl = floorf(expo);
-    if (fl == expo && expo >= 0.0f && expo <= 4096.0f) {
-        uint32_t n = static_cast<uint32_t>(expo);
-        double r = 1.0, b = static_cast<double>(base);
-        while (n != 0u) {
-            if (n & 1u) r = r * b;
-            b = b * b;
-            n >>= 1;
+// powf(cosphi, Ns) of phongShade (flyscene.cpp:852).  The reference calls libm's powf: glibc 2.35's e_powf.c (the ARM "optimized
+// routines" algorithm: log2 through a 16-entry table + degree-5 polynomial, exp2 through a 32-entry table + degree-3 polynomial, all
+// in double) in the build the x86-64 ifunc selects on FMA+AVX2 CPUs.  That published algorithm is evaluated here with the same
+// tables, the same operation order and fused multiply-adds at the same places, so the result is the libm result BIT FOR BIT and
+// the float accumulators of the frame equal the CPU path's exactly (the tests compare with tolerance 0).
+__device__ const double POWF_LOG2_INVC[16] = {0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010bp+0, 0x1.3c995b0b80385p+0, 0x1.30d190c8864a5p+0,
+                                              0x1.25e227b0b8eap+0, 0x1.1bb4a4a1a343fp+0, 0x1.12358f08ae5bap+0, 0x1.0953f419900a7p+0, 0x1p+0,
+                                              0x1.e608cfd9a47acp-1, 0x1.ca4b31f026aap-1, 0x1.b2036576afce6p-1, 0x1.9c2d163a1aa2dp-1, 0x1.886e6037841edp-1,
+                                              0x1.767dcf5534862p-1};
+__device__ const double POWF_LOG2_LOGC[16] = {-0x1.efec65b963019p-2, -0x1.b0b6832d4fca4p-2, -0x1.7418b0a1fb77bp-2, -0x1.39de91a6dcf7bp-2, -0x1.01d9bf3f2b631p-2,
+                                              -0x1.97c1d1b3b7afp-3, -0x1.2f9e393af3c9fp-3, -0x1.960cbbf788d5cp-4, -0x1.a6f9db6475fcep-5, 0x0p+0,
+                                              0x1.338ca9f24f53dp-4, 0x1.476a9543891bap-3, 0x1.e840b4ac4e4d2p-3, 0x1.40645f0c6651cp-2, 0x1.88e9c2c1b9ff8p-2,
+                                              0x1.ce0a44eb17bccp-2};
+__device__ const unsigned long long POWF_EXP2_TAB[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
+    0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
+    0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+__device__ __forceinline__ float pow_shininess(const float x, const float y) {
+    uint32_t ix = __float_as_uint(x);
+    const uint32_t iy = __float_as_uint(y);
+    const bool y_special = (2u * iy - 1u) >= (2u * 0x7f800000u - 1u);                 // y is 0, inf or NaN
+    if (!(ix - 0x00800000u < 0x7f800000u - 0x00800000u) || y_special) {
+        // the cases e_powf.c answers without arithmetic (x >= 0 here: cosphi = max(0, .)), then subnormal x
+        if (2u * iy == 0u) return 1.0f;                                                // pow(x, +-0) = 1
+        if (x == 1.0f) return 1.0f;
+        if (x != x || y != y) return x + y;                                            // NaN
+        if (2u * iy == 2u * 0x7f800000u) {                                             // y = +-inf
+            const bool small = 2u * ix < 2u * 0x3f800000u;                            // |x| < 1
+            return (small == ((iy >> 31) != 0u)) ? __uint_as_float(0x7f800000u) : 0.0f;
         }
-        return static_cast<float>(r);
+        if (2u * ix == 0u) return (iy >> 31) ? __uint_as_float(0x7f800000u) : 0.0f;    // pow(+0, y): 0 for y > 0, +inf for y < 0
+        if (ix == 0x7f800000u) return (iy >> 31) ? 0.0f : x;                           // pow(+inf, y)
+        if (ix >> 31) return __uint_as_float(0x7fc00000u);                             // negative x: not reachable from phongShade
+        // subnormal x: normalise as e_powf.c does
+        ix = __float_as_uint(x * 0x1p23f);
+        ix &= 0x7fffffffu;
+        ix -= 23u << 23;
     }
-    return static_cast<float>(pow(static_cast<double>(base), static_cast<double>(expo)));
+    // log2_inline
+    const uint32_t tmp = ix - 0x3f330000u;
+    const uint32_t i = (tmp >> 19) & 15u;
+    const uint32_t top = tmp & 0xff800000u;
+    const int k = static_cast<int>(top) >> 23;
+    const double z = static_cast<double>(__uint_as_float(ix - top));
+    const double r = __builtin_fma(z, POWF_LOG2_INVC[i], -1.0);
+    const double y0 = POWF_LOG2_LOGC[i] + static_cast<double>(k);
+    const double r2 = r * r;
+    const double yy = __builtin_fma(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
+    const double p = __builtin_fma(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
+    const double r4 = r2 * r2;
+    double q = __builtin_fma(0x1.71547652ab82bp+0, r, y0);
+    q = __builtin_fma(p, r2, q);
+    const double logx = __builtin_fma(yy, r4, q);
+    const double ylogx = static_cast<double>(y) * logx;
+    if (((static_cast<unsigned long long>(__double_as_longlong(ylogx)) >> 47) & 0xffffull) >= 0x80bfull) {       // |y * log2(x)| >= 126
+        if (ylogx > 0x1.fffffffd1d571p+6) return __uint_as_float(0x7f800000u);       // __math_oflowf
+        if (ylogx <= -150.0) return 0.0f;                                              // __math_uflowf
+        if (ylogx < -149.0) return __uint_as_float(1u);                                // __math_may_uflowf: the smallest subnormal
+    }
+    // exp2_inline
+    double kd = ylogx + 0x1.8p+47;
+    const unsigned long long ki = static_cast<unsigned long long>(__double_as_longlong(kd));
+    kd -= 0x1.8p+47;
+    const double rr = ylogx - kd;
+    const unsigned long long t = POWF_EXP2_TAB[ki & 31ull] + (ki << 47);
+    const double sc = __longlong_as_double(static_cast<long long>(t));
+    const double zz = __builtin_fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
+    const double rr2 = rr * rr;
+    double yv = __builtin_fma(0x1.62e42ff0c52d6p-1, rr, 1.0);
+    yv = __builtin_fma(zz, rr2, yv);
+    yv = yv * sc;
+    return static_cast<float>(yv);
 }
 
 __device__ __forceinline__ float fresnel_term(float ix, float iy, float iz, float nx, float ny, float nz, float ior) {

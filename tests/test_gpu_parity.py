@@ -1,9 +1,10 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle, on a real MI355X.
 
 Bars (BASELINE.json north_star): integer results -- closest-hit face ids, ray/box/triangle-reference counters, the
-visibility bits, pixel indices -- are BIT-EXACT; float RGB is within 1e-5 of the CPU accumulator (the only
-non-identical operation is powf: glibc on the CPU, double-precision pow rounded once on the device); 8-bit PPM
-values may therefore differ by +-1 on at most 1e-5 of the values (observed: 0).
+visibility bits, pixel indices, the 8-bit PPM values -- are BIT-EXACT, and so is the float RGB accumulator: every operation keeps the
+reference's order and rounding, and powf -- the one libm call on the path -- is glibc's published algorithm evaluated bit for bit on
+the device (rt_kernels.hip: pow_shininess; oracle: orc_powf, pinned to the host's powf by tests/test_powf.py).  The north star allows
+1e-5 on the float RGB; the tests hold the path to 0.
 """
 import hashlib
 import json
@@ -16,8 +17,8 @@ import scenes_gen
 
 pytestmark = pytest.mark.gpu
 
-RGB_TOL = 1e-5           # stated tolerance for float RGB (north_star)
-Q_FRACTION = 1e-5        # tolerated fraction of 8-bit values off by one (powf ulp at a quantisation boundary)
+RGB_TOL = 0.0            # float RGB: bit-identical accumulators (the north star's stated tolerance is 1e-5)
+Q_FRACTION = 0.0         # 8-bit PPM values: all equal
 KA = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "survey_known_answers.json")))
 
 
@@ -59,7 +60,7 @@ def assert_frame_parity(oracle, rgb, hits, ref, rhits):
     q, rq = oracle.quantise(rgb), oracle.quantise(ref)
     bad = q != rq
     assert np.abs(q - rq).max() <= 1
-    assert bad.sum() <= max(1, int(Q_FRACTION * q.size)), f"{int(bad.sum())} 8-bit values differ"
+    assert bad.sum() <= int(Q_FRACTION * q.size), f"{int(bad.sum())} 8-bit values differ"
     return err, int(bad.sum())
 
 
