@@ -85,12 +85,14 @@ void Flyscene::raytraceScene(int width, int height) {
     image_.assign(static_cast<size_t>(width) * height * 3, 0.f);
     std::cout << "Ray tracing ..." << std::endl;
     const rt_status s = rt_render(ctx_, &camera_, &L, &p, image_.data(), nullptr, &stats_);
+    last_status_ = s;
     if (s != RT_OK) {
         std::cerr << "rt_mi355x: render failed: " << rt_last_error(ctx_) << std::endl;
         return;
     }
     std::cout << "Writting to restult.ppm ... " << std::endl;
-    rt_write_ppm(output_path_.c_str(), image_.data(), width, height);
+    last_status_ = rt_write_ppm(output_path_.c_str(), image_.data(), width, height);
+    if (last_status_ != RT_OK) { std::cerr << "rt_mi355x: cannot write " << output_path_ << std::endl; return; }
     const std::chrono::duration<double> el = std::chrono::high_resolution_clock::now() - t0;
     std::cout << "Writting to restult.ppm done!" << std::endl << std::endl << "ray tracing done! " << std::endl;
     std::cout << "ELAPSED TIME:" << el.count() << std::endl;

@@ -47,6 +47,8 @@ public:
     void setOutputPath(const std::string &p) { output_path_ = p; }
     void setDevice(int d) { device_ = d; }
     const rt_stats &lastStats() const { return stats_; }
+    // status of the last raytraceScene() (the reference's member is void; a headless caller needs to know): RT_OK or a negative rt_status
+    rt_status lastStatus() const { return last_status_; }
     const std::vector<float> &lastImage() const { return image_; }
     rt_camera *getCamera() { return &camera_; }
     std::vector<Vec3f> &getLights() { return lights_; }
@@ -64,6 +66,7 @@ private:
     int usteps_ = 5, vsteps_ = 5, max_depth_ = -1, device_ = 0;
     int view_w_ = 0, view_h_ = 0;
     rt_stats stats_{};
+    rt_status last_status_ = RT_OK;
     std::vector<float> image_;
 };
 

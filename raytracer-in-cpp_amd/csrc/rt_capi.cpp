@@ -85,6 +85,8 @@ struct rt_ctx {
     DCam *h_cam_ring = nullptr;       // pinned staging ring for asynchronous camera uploads
     uint32_t cam_slot = 0;
     uint64_t frame_generation = 0;    // bumped whenever the frame buffers are reallocated (invalidates captured graphs)
+    uint64_t scene_generation = 0;    // bumped by every rt_upload_scene: a captured graph holds the scene's device pointers by value
+    hipEvent_t cam_events[512] = {};  // one per camera-ring slot: recorded after the slot's H2D copy, waited for before the slot is reused
     float *d_rgb = nullptr;      // staging for rt_render (host output)
     int32_t *d_hit = nullptr;
     float *d_t = nullptr;
@@ -113,6 +115,7 @@ extern "C" const char *rt_version(void) { return "rt_mi355x 0.1 (gfx950)"; }
 
 extern "C" const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->err.c_str() : k_no_ctx; }
 
+extern "C" void rt_destroy(rt_ctx *c);
 extern "C" rt_status rt_create(rt_ctx **out, int device) {
     if (!out) return RT_ERR_INVALID;
     *out = nullptr;
@@ -146,6 +149,7 @@ extern "C" rt_status rt_create(rt_ctx **out, int device) {
         delete c;
         return RT_ERR_HIP;
     }
+    if (hipMemset(c->d_ctl, 0, sizeof(Control)) != hipSuccess) { rt_destroy(c); return RT_ERR_HIP; }
     *out = c;
     return RT_OK;
 }
@@ -186,6 +190,7 @@ extern "C" void rt_destroy(rt_ctx *c) {
     if (c->d_cam) (void)hipFree(c->d_cam);
     if (c->h_cam_ring) (void)hipHostFree(c->h_cam_ring);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->cam_events) if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -389,7 +394,9 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
         if (il == 9 || il == 6 || (il > 2 && il < 6)) c->reflective = true;
     }
 
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // nothing in flight may still read the old scene
     free_scene(c);
+    ++c->scene_generation;
     rt_status st;
     // device nodes = public nodes + content boxes, bottom-up (children always follow their parent in the array)
     std::vector<DNode> dnodes(sc->n_nodes);
@@ -547,6 +554,18 @@ static hipEvent_t event_at(rt_ctx *c, size_t i) {
     return c->events[i];
 }
 
+// asynchronous camera upload through the pinned ring: a slot is only rewritten after the copy that last read it has completed
+static rt_status upload_camera(rt_ctx *c, const DCam &dc, hipStream_t st) {
+    const uint32_t slot_i = c->cam_slot++ % kCamRing;
+    if (c->cam_events[slot_i]) HIPCHK(c, hipEventSynchronize(c->cam_events[slot_i]));
+    else HIPCHK(c, hipEventCreateWithFlags(&c->cam_events[slot_i], hipEventDisableTiming));
+    DCam *slot = &c->h_cam_ring[slot_i];
+    *slot = dc;
+    HIPCHK(c, hipMemcpyAsync(c->d_cam, slot, sizeof(DCam), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->cam_events[slot_i], st));
+    return RT_OK;
+}
+
 // One frame = memset(control) ; per level { trace ; shadow ; shade } ; resolve -- no host synchronisation inside.
 static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLights &L, DFrame F, bool primary, bool count,
                            float *d_rgb, uint8_t *d_u8, int32_t *d_hit, float *d_t, int timed, uint32_t n_input_rays) {
@@ -559,14 +578,13 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
     rt_status s = ensure_frame(c, F.npix, D + 1, P, tiles, static_cast<size_t>(lslots));
     if (s != RT_OK) return s;
     F.item_cap = F.ray_cap = list_cap(tiles);
-    HIPCHK(c, hipMemsetAsync(c->d_ctl, 0, sizeof(Control), st));
+    HIPCHK(c, hipMemsetAsync(c->d_ctl, 0, kFrameClearBytes, st));        // everything but the sticky overflow word
     launch_set_prof(st, c->d_ctl);   // no-op unless built with -DRT_PROFILE
     if (!primary) HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->d_ctl->n_rays[0][0]), static_cast<int>(n_input_rays), 1, st));
     size_t ev = c->ev_base;
-    if (cam) {   // asynchronous camera upload through the pinned ring (skipped when replaying a captured graph)
-        DCam *slot = &c->h_cam_ring[c->cam_slot++ % kCamRing];
-        *slot = *cam;
-        HIPCHK(c, hipMemcpyAsync(c->d_cam, slot, sizeof(DCam), hipMemcpyHostToDevice, st));
+    if (cam) {   // (skipped when replaying a captured graph)
+        rt_status cs = upload_camera(c, *cam, st);
+        if (cs != RT_OK) return cs;
     }
     // timed == 1: an event between every pair of launches (per-kernel breakdown; adds ~4 us per boundary)
     // timed == 2: lean set for timed loops -- frame start, around each k_shadow launch, frame end
@@ -645,7 +663,11 @@ static rt_status sum_frame_times(rt_ctx *c, size_t ev, int levels_run, rt_stats 
 static rt_status check_overflow(rt_ctx *c) {
     uint32_t ov = 0;
     HIPCHK(c, hipMemcpy(&ov, &c->d_ctl->overflow, sizeof ov, hipMemcpyDeviceToHost));
-    if (ov) { c->err = "internal: a compaction list overflowed its capacity; the frame is incomplete"; return RT_ERR_HIP; }
+    if (ov) {
+        HIPCHK(c, hipMemset(&c->d_ctl->overflow, 0, sizeof ov));
+        c->err = "internal: a compaction list overflowed its capacity; a frame since the last synchronising call is incomplete";
+        return RT_ERR_HIP;
+    }
     return RT_OK;
 }
 
@@ -653,7 +675,7 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
     HIPCHK(c, hipStreamSynchronize(st));
     Control h;
     HIPCHK(c, hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
-    if (h.overflow) { c->err = "internal: a compaction list overflowed its capacity; the frame is incomplete"; return RT_ERR_HIP; }
+    { const rt_status os_ = check_overflow(c); if (os_ != RT_OK) return os_; }
     fold_stats(h);
     if (std::getenv("RT_DEBUG")) std::fprintf(stderr, "RT_DEBUG level0: items %u tasks closest %u %u centre %u %u shadow %u %u\n", [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_items[0][sh * 16]; return t; }(), h.n_tasks[0][0], 0u, h.n_tasks[0][1], 0u, [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_task_sh[0][sh * 16]; return t; }(), 0u);
     out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample;
@@ -786,7 +808,7 @@ struct rt_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     DFrame F{};
-    uint64_t generation = 0;
+    uint64_t generation = 0, scene_generation = 0;
     hipStream_t last_stream = nullptr;
 };
 
@@ -808,7 +830,7 @@ extern "C" rt_status rt_graph_create(rt_ctx *c, const rt_lights *lights, const r
     if ((s = ensure_frame(c, F.npix, F.max_depth + 1, P, frame_tiles(F), static_cast<size_t>(L.n_lights))) != RT_OK) return s;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     rt_graph *g = new rt_graph();
-    g->ctx = c; g->F = F; g->generation = c->frame_generation;
+    g->ctx = c; g->F = F; g->generation = c->frame_generation; g->scene_generation = c->scene_generation;
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { delete g; c->err = "hipStreamBeginCapture failed"; return RT_ERR_HIP; }
     s = run_frame(c, c->stream, nullptr, L, F, true, false, d_out_rgb, d_out_u8, nullptr, nullptr, 0, 0);
     const hipError_t e = hipStreamEndCapture(c->stream, &g->graph);
@@ -832,13 +854,13 @@ extern "C" rt_status rt_graph_launch(rt_graph *g, const rt_camera *cam, void *st
     if (!g || !cam) return RT_ERR_INVALID;
     rt_ctx *c = g->ctx;
     if (g->generation != c->frame_generation) { c->err = "rt_graph_launch: the frame buffers were reallocated after capture; re-create the graph"; return RT_ERR_INVALID; }
+    if (g->scene_generation != c->scene_generation) { c->err = "rt_graph_launch: a scene was uploaded after capture (the graph holds the old scene's device pointers); re-create the graph"; return RT_ERR_INVALID; }
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
     DCam dc;
     make_cam(cam, &dc);
-    DCam *slot = &c->h_cam_ring[c->cam_slot++ % kCamRing];
-    *slot = dc;
-    HIPCHK(c, hipMemcpyAsync(c->d_cam, slot, sizeof(DCam), hipMemcpyHostToDevice, st));
+    rt_status cs = upload_camera(c, dc, st);
+    if (cs != RT_OK) return cs;
     HIPCHK(c, hipGraphLaunch(g->exec, st));
     g->last_stream = st;
     return RT_OK;
@@ -848,6 +870,7 @@ extern "C" rt_status rt_graph_stats(rt_graph *g, rt_stats *out) {
     if (!g || !out) return RT_ERR_INVALID;
     rt_ctx *c = g->ctx;
     std::memset(out, 0, sizeof *out);
+    if (g->scene_generation != c->scene_generation) { c->err = "rt_graph_stats: a scene was uploaded after capture; re-create the graph"; return RT_ERR_INVALID; }
     HIPCHK(c, hipSetDevice(c->device));
     const int levels_run = c->reflective ? g->F.max_depth + 1 : 1;
     return fill_stats(c, g->last_stream ? g->last_stream : c->stream, g->F, levels_run, false, out, false);
@@ -870,7 +893,7 @@ extern "C" rt_status rt_timing_collect(rt_ctx *c, rt_stats *out) {
     HIPCHK(c, hipStreamSynchronize(c->pending_stream));
     Control h;
     HIPCHK(c, hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
-    if (h.overflow) { c->err = "internal: a compaction list overflowed its capacity; a frame is incomplete"; return RT_ERR_HIP; }
+    { const rt_status os_ = check_overflow(c); if (os_ != RT_OK) return os_; }
     fold_stats(h);
     out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample;
     out->pixels = c->pending_frame.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;

@@ -13,6 +13,7 @@
 //   fres       float [(D+1) * npix]           Fresnel factor of illum-5 hits
 #pragma once
 
+#include <cstddef>
 #include <cstdint>
 
 #include "rt_mi355x.h"
@@ -178,8 +179,6 @@ struct Control {
     // leaf tasks of the shadow kernels: RT_LIST_SHARDS sub-queues (producer block % RT_LIST_SHARDS), each counter on its own line --
     // one returning atomic per emitting leaf visit on a SINGLE word (~60k per dodge launch) ran into the ~88 per us limit
     uint32_t n_task_sh[RT_MAX_DEPTH + 1][RT_LIST_SHARDS * 16];
-    uint32_t overflow;                               // set by a kernel whose list reservation did not fit (never expected: the
-                                                     // capacities are derived from the tile counts); the host turns it into an error
     // totals, filled on the HOST by fold_stats() from the sharded counters below
     unsigned long long rays_primary, rays_bounce, rays_centre, rays_sample, pixels_culled, shaded_hits;
     unsigned long long box_tests, leaf_tri_refs;              // k_trace (closest hit + light-centre rays)
@@ -190,7 +189,12 @@ struct Control {
     unsigned long long stat[RT_STAT_SHARDS][16];
     // -DRT_PROFILE builds only: executed work (wave steps) and useful lane work per leaf mode / box tests
     unsigned long long prof[640];
+    // LAST member, NOT covered by the per-frame memset (kFrameClearBytes): set by a kernel whose list reservation did not fit (never
+    // expected: the capacities are derived from the tile counts).  Sticky, so that asynchronous frames (rt_render_device without stats,
+    // graph replays) cannot lose it; every synchronising entry point turns it into an error and clears it.
+    uint32_t overflow;
 };
+static const size_t kFrameClearBytes = offsetof(Control, overflow);
 
 inline void fold_stats(Control &h) {
     unsigned long long t[16] = {0};

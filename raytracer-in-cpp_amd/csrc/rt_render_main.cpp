@@ -22,6 +22,7 @@ int main(int argc, char **argv) {
     if (w <= 0 || h <= 0) return 2;
     scene.initialize(w, h);
     scene.raytraceScene();
+    if (scene.lastStatus() != RT_OK) return 1;          // no result.ppm was written: say so with the exit code
     const rt_stats &st = scene.lastStats();
     std::printf("device ms: trace %.3f shadow %.3f shade %.3f resolve %.3f total %.3f\n", st.ms_trace, st.ms_shadow, st.ms_shade, st.ms_resolve, st.ms_total);
     return 0;

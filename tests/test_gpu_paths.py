@@ -1,0 +1,168 @@
+"""Paths round 1 left untested: OBJ without materials (toy.obj -> the default Mtl), Flyscene::modifyTriangle's model matrix with and
+without a tree rebuild (flyscene.cpp:998-1015), scenes far from unit scale (the culling margins are relative to the scene extent), and
+the scene-generation check of captured hipGraphs.  GPU vs the oracle: face ids, 8-bit values AND float RGB bit-exact.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SCENES = os.path.join(HERE, "golden", "scenes")
+
+
+def scaled_camera_and_lights(rt, oracle, w, h, s, usteps):
+    """the default camera / light of the reference moved to a scene scaled by s about the origin (plain structs on both sides)"""
+    cam = rt.default_camera(w, h)
+    ocam = oracle.camera(w, h)
+    for c in (cam, ocam):
+        for k in range(3):
+            c.center[k] = np.float32(c.center[k]) * np.float32(s)
+        for r in range(3):
+            c.inv_view[r * 4 + 3] = np.float32(c.inv_view[r * 4 + 3]) * np.float32(s)
+    L = rt.make_lights(area=True, usteps=usteps, vsteps=usteps)
+    oL = oracle.lights(area=True, usteps=usteps, vsteps=usteps)
+    for l in (L, oL):
+        for k in range(3):
+            l.pos[0][k] = np.float32(l.pos[0][k]) * np.float32(s)
+        l.len_x = np.float32(l.len_x) * np.float32(s)
+        l.len_y = np.float32(l.len_y) * np.float32(s)
+    return cam, ocam, L, oL
+
+
+def render_gpu(rt, ctx, cam, L, w, h, depth):
+    p = rt.make_params(w, h, depth)
+    rgb = np.zeros((h, w, 3), np.float32)
+    hits = np.zeros((h, w), np.int32)
+    st = ctx.lib.rt_render(ctx.handle, C.byref(cam), C.byref(L), C.byref(p), rgb.ctypes.data_as(C.c_void_p), hits.ctypes.data_as(C.c_void_p), None)
+    rt.capi.check(ctx.lib, ctx.handle, st, "rt_render")
+    return rgb, hits
+
+
+def assert_exact(oracle, rgb, hits, ref, rhits):
+    assert np.array_equal(hits, rhits), f"{int((hits != rhits).sum())} closest-hit face ids differ"
+    assert np.array_equal(rgb.view(np.uint32), ref.view(np.uint32)), f"max |RGB - oracle| = {float(np.abs(rgb - ref).max())}"
+    assert (rhits >= 0).sum() > 0.02 * rhits.size, "the frame must actually show the object"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("u", [5, 8])
+def test_toy_obj_without_materials_uses_the_default_mtl(rt, oracle, u):
+    """resources/models/toy.obj has no mtllib: every face keeps material_id -1, which the reference indexes (UB, flyscene.cpp:712); the
+    defined behaviour here and in the oracle is Tucano's default-constructed Mtl (mtl.hpp:21-39: kd .5, ks 1, Ns 10, illum 0).
+    No reference render exists for it: parity unpinned beyond the oracle."""
+    path = os.path.join(SCENES, "toy.obj")
+    hs = rt.HostScene(path, 1000, 15)
+    assert hs.info()["nodes"] == 73
+    ctx = rt.Context(0)
+    ctx.upload(hs)
+    osc = oracle.load_scene(path)
+    w, h = 224, 160
+    rgb, hits = render_gpu(rt, ctx, rt.default_camera(w, h), rt.make_lights(area=True, usteps=u, vsteps=u), w, h, 4)
+    ref, rhits, _ = osc.render(oracle.camera(w, h), oracle.lights(area=True, usteps=u, vsteps=u), w, h, max_depth=4, threads=8, want_hits=True)
+    assert_exact(oracle, rgb, hits, ref, rhits)
+    osc.close(); ctx.close(); hs.close()
+
+
+MODEL = [0.75, 0.0, 0.0, 0.12, 0.0, 0.75, 0.0, -0.08, 0.0, 0.0, 0.75, 0.05]      # scale 0.75 + translate, 3x4 row-major
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rebuild", [True, False])
+@pytest.mark.parametrize("scene", ["cube.obj", "dodgeColorTest.obj"])
+def test_model_matrix_with_and_without_rebuild(rt, oracle, scene, rebuild):
+    """Flyscene::modifyTriangle (flyscene.cpp:998-1015) sets the model matrix and leaves the octree STALE: rays then walk the old boxes but
+    test the moved triangles, and phongShade's normal = (model * n).normalized() picks up the translation (Affine * Vector3f).
+    rebuild = False reproduces exactly that; rebuild = True is the extension (tree rebuilt over the moved vertices)."""
+    path = os.path.join(SCENES, scene)
+    hs = rt.HostScene(path, 1000, 15)
+    hs.set_model(MODEL, rebuild)
+    ctx = rt.Context(0)
+    ctx.upload(hs)
+    osc = oracle.load_scene(path)
+    osc.set_model(MODEL)
+    if rebuild:
+        osc.rebuild()
+    w, h = 200, 152
+    rgb, hits = render_gpu(rt, ctx, rt.default_camera(w, h), rt.make_lights(area=True, usteps=8, vsteps=8), w, h, 3)
+    ref, rhits, _ = osc.render(oracle.camera(w, h), oracle.lights(area=True, usteps=8, vsteps=8), w, h, max_depth=3, threads=8, want_hits=True)
+    assert_exact(oracle, rgb, hits, ref, rhits)
+    osc.close(); ctx.close(); hs.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("s", [1000.0, 0.001])
+@pytest.mark.parametrize("scene", ["cube.obj", "dodgeColorTest.obj"])
+def test_scene_scale_1e3_and_1e_minus_3(rt, oracle, scene, s, monkeypatch):
+    """Every culling margin (content / chunk boxes, shaft planes, plane culling, the verified slab test) is relative to the scene's
+    extent: a scene scaled by 1e3 or 1e-3 (model matrix, tree rebuilt) with camera and light scaled along must give the oracle's frame
+    bit for bit, and the culled render must equal the RT_NO_CULL=1 render."""
+    path = os.path.join(SCENES, scene)
+    m = [s, 0.0, 0.0, 0.0, 0.0, s, 0.0, 0.0, 0.0, 0.0, s, 0.0]
+    w, h, u = 176, 128, 8
+    cam, ocam, L, oL = scaled_camera_and_lights(rt, oracle, w, h, s, u)
+    hs = rt.HostScene(path, 1000, 15)
+    hs.set_model(m, True)
+    ctx = rt.Context(0)
+    ctx.upload(hs)
+    rgb, hits = render_gpu(rt, ctx, cam, L, w, h, 4)
+    osc = oracle.load_scene(path)
+    osc.set_model(m)
+    osc.rebuild()
+    ref, rhits, _ = osc.render(ocam, oL, w, h, max_depth=4, threads=8, want_hits=True)
+    # (model * n).normalized() of a scaled normal: the translation part is zero here, so the picture is the unit-scale one
+    assert_exact(oracle, rgb, hits, ref, rhits)
+    monkeypatch.setenv("RT_NO_CULL", "1")
+    ctx2 = rt.Context(0)
+    ctx2.upload(hs)
+    rgb2, hits2 = render_gpu(rt, ctx2, cam, L, w, h, 4)
+    assert np.array_equal(hits, hits2) and np.array_equal(rgb.view(np.uint32), rgb2.view(np.uint32))
+    osc.close(); ctx.close(); ctx2.close(); hs.close()
+
+
+@pytest.mark.gpu
+def test_graph_is_rejected_after_scene_reupload(rt):
+    """A captured hipGraph holds the scene's device pointers by value: re-uploading a scene must invalidate it."""
+    hs = rt.HostScene(os.path.join(SCENES, "cube.obj"), 1000, 15)
+    ctx = rt.Context(0)
+    ctx.upload(hs)
+    import torch
+    w, h = 64, 48
+    out = torch.zeros(w * h * 3, dtype=torch.float32, device="cuda")
+    L = rt.make_lights(area=True, usteps=5, vsteps=5)
+    g = rt.FrameGraph(ctx, L, rt.make_params(w, h, 2), out.data_ptr(), 0)
+    cam = rt.default_camera(w, h)
+    g.launch(cam, 0)
+    torch.cuda.synchronize()
+    ctx.upload(hs)                                    # frees and reallocates every scene buffer
+    st = ctx.lib.rt_graph_launch(g.handle, C.byref(cam), None)
+    assert st == rt.capi.RT_ERR_INVALID
+    assert b"scene" in ctx.lib.rt_last_error(ctx.handle)
+    g.close(); ctx.close(); hs.close()
+
+
+def test_set_model_rebuild_arrays_equal_oracle(rt, oracle):
+    """CPU: rt_host_scene_set_model(rebuild) against orc_set_model_matrix + orc_build_tree -- world vertices and tree summary."""
+    path = os.path.join(SCENES, "dodgeColorTest.obj")
+    hs = rt.HostScene(path, 1000, 15)
+    hs.set_model(MODEL, True)
+    osc = oracle.load_scene(path)
+    osc.set_model(MODEL)
+    osc.rebuild()
+    a = hs.arrays()
+    oa = osc.arrays()
+    tri = oa["wverts"][oa["face_vid"].reshape(-1)].reshape(-1, 9)
+    assert np.array_equal(a["tri_verts"].view(np.uint32), tri.view(np.uint32))
+    nodes = [osc.node(i) for i in range(osc.nnodes)]
+    leaves = [n for n in nodes if n["is_leaf"] and not n["is_empty"] and n["nfaces"] > 0]
+    info = hs.info()
+    assert info["leaves"] == len(leaves) and info["face_refs"] == sum(n["nfaces"] for n in leaves)
+    assert np.array_equal(np.array(info["root_box"], np.float32).view(np.uint32), nodes[0]["box"].view(np.uint32))
+    # without a rebuild the tree keeps the boxes of the unmoved mesh
+    hs2 = rt.HostScene(path, 1000, 15)
+    box0 = hs2.arrays()["node_box"].copy()
+    hs2.set_model(MODEL, False)
+    assert np.array_equal(hs2.arrays()["node_box"].view(np.uint32), box0.view(np.uint32))
+    assert np.array_equal(hs2.arrays()["tri_verts"].view(np.uint32), tri.view(np.uint32))
+    osc.close(); hs.close(); hs2.close()
