@@ -5,13 +5,34 @@
 A "step" is one whole frame: primary generation + closest hit + light-centre visibility + area-light sample
 shadow rays + shading + bounces + resolve/quantise (+ the RCCL row gather when N > 1).  Inputs (flattened octree,
 triangle records, materials) are resident in HBM before the timed region; output stays on the device.
-`value` = rays of the whole frame (all ranks) per second, a ray being one traversal query as SURVEY.md §8(d) defines it.
+`value` = rays of the whole frame (all ranks) per second, a ray being one traversal query as SURVEY.md 8(d) defines it.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--scene cube|dodge] [--width 1920 --height 1080 --grid 8 --depth 4]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scene cube|dodge|wavy] [--width 1920 --height 1080 --grid 8 --depth 4]
 N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL).
+
+The headline (`value`) is the configured default scene, cube.obj -- a 1-node tree, i.e. the FLAT kernels.  The plain N = 1 invocation
+therefore ALSO times the two tree scenes with the same code and reports them under `tree_scenes` with their own ms_per_step,
+per-kernel times, roofline and cpu_baseline: dodgeColorTest.obj at the headline settings and BASELINE cfg4 (3840x2160, depth 8,
+256 samples, ~1M-triangle synthetic mesh).
+
+Roofline.  The path is traversal / branch bound and its scenes are cache resident: the bound that limits the kernels is VALU ISSUE, not
+HBM and not MFMA.  `roofline` therefore reports (all <= 1 by construction, all from THIS run unless marked `constant`):
+  * achieved = modelled VALU wave-instructions of the dominant kernel (k_shadow: area-light sample shadow rays) -- the wave-level STEP
+    COUNTS the shipped kernels executed for this very frame (counted by the same sources built with step counters,
+    librt_mi355x_work.so, in an untimed pass) x the instruction cost of each step kind -- per SIMD per ns of the live
+    launch time (HIP events on the launch stream inside the timed region); peak = the plain-FP32 issue rate measured on this chip
+    (tools/micro/valu_rate.hip: 0.967 wave-instructions per SIMD per ns); `useful_frac` counts only the reference's own arithmetic
+    (boxIntersect + rayTriangleIntersection evaluations), `frac` everything the kernel has to issue;
+  * executed_valu: the hardware's own instruction count (SQ_INSTS_VALU, its own rocprofv3 --pmc pass, profiles/valu.json) over the live
+    time -- a CONSTANT from profiles/, quoted only while profiles/valu.json carries the sha256 of the kernels source it was taken with;
+  * traffic / hbm_frac: HBM bytes per launch from the TCC counters (profiles/traffic.json, same stamping) and their share of 8 TB/s;
+  * reference_semantics_bytes: SURVEY 8(d)'s algorithmic-byte figure (24 B x box tests + 52 B x leaf triangle refs, every triangle of
+    every intersected leaf, no early-out), counted exactly by the COUNT kernel variants.  Divided by the launch time it EXCEEDS the
+    HBM peak (the culling skips most of that work exactly), so it is reported as a workload size, not as a utilisation.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -20,9 +41,390 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-VALU_PEAK_PER_SIMD_NS = 0.967   # measured: tools/micro/valu_rate.hip (plain FP32 wave64 ops, 8 waves/SIMD), 256 CUs x 4 SIMDs
-HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
-BOX_BYTES, TRI_REF_BYTES = 24, 52   # SURVEY.md §8(d): algorithmic bytes per box test / per leaf triangle reference
+VALU_PEAK_PER_SIMD_NS = 0.967   # measured: tools/micro/valu_rate.hip (plain FP32 wave64 ops, 8 waves/SIMD)
+N_SIMDS = 1024                  # 256 CUs x 4 SIMDs
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+BOX_BYTES, TRI_REF_BYTES = 24, 52   # SURVEY.md 8(d): algorithmic bytes per box test / per leaf triangle reference
+RT_WORK_SHADOW = 640            # rt_device.hpp: offset of the shadow kernels' step counters in Control::prof
+
+# VALU wave-instructions per wave-level step (read off the gfx950 listing of the shipped kernels, `make isa`)
+COST = {
+    "tri_lanes_triangles": 58,   # one ray broadcast against the 64 triangles of a chunk: rayTriangleIntersection + 6 v_readlane
+    "tri_lanes_rays": 45,        # one triangle against the wave's 64 rays (scalar / LDS-staged leaves, flat scenes)
+    "node_per_ray": 72,          # a surviving child: 16 v_readlane + content test (25) + verified boxIntersect (~30)
+    "box_stack_walk": 55,        # stack walk (packet_walk) child: content test + verified boxIntersect
+    "shaft_group": 75,           # lane = (child, test): two separating tests + ballots + byte reduction
+    "leaf_chunk_batch": 45,      # lane = (chunk, test) on 8 chunk bounds
+    "chunk_per_ray": 34,         # per-ray conservative chunk test (7 v_readlane + 25)
+    "unit_shaft": 180,           # k_shadow_shaft per unit: item, sample, root test, shaft planes, queue
+    "unit_flat": 250,            # flat k_shadow per unit: item, sample, root test, plane culling, queue
+    "unit_stack": 200,
+}
+
+
+def kernels_sha():
+    return hashlib.sha256(open(os.path.join(ROOT, "raytracer-in-cpp_amd", "csrc", "rt_kernels.hip"), "rb").read()).hexdigest()
+
+
+def scene_of(name):
+    if name == "wavy":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import scenes_gen
+        import tempfile
+        return ("wavy708.obj (synthetic 708x708 displaced grid + floor, 1,002,530 triangles)",
+                scenes_gen.wavy_grid(os.path.join(tempfile.gettempdir(), f"rt_wavy_{os.getpid()}"), n=708))
+    f = {"cube": "cube.obj", "dodge": "dodgeColorTest.obj"}[name]
+    return f, os.path.join(ROOT, "tests", "golden", "scenes", f)
+
+
+def work_counters(pkg, hs, W, H, G, D):
+    """one untimed frame on the counting build (same kernel sources + wave-level step counters): what the shipped kernels executed"""
+    capi = pkg.capi
+    path = os.path.join(ROOT, "raytracer-in-cpp_amd", "lib", "librt_mi355x_work.so")
+    if not os.path.exists(path):
+        return None
+    import numpy as np
+    lib = capi.load_library(path)
+    ctx = C.c_void_p()
+    if lib.rt_create(C.byref(ctx), 0) != capi.RT_OK:
+        return None
+    try:
+        capi.check(lib, ctx, lib.rt_upload_scene(ctx, C.byref(hs.view)), "work: rt_upload_scene")
+        cam = pkg.default_camera(W, H)
+        L = pkg.make_lights(area=True, usteps=G, vsteps=G)
+        p = pkg.make_params(W, H, D)
+        rgb = np.zeros(W * H * 3, np.float32)
+        capi.check(lib, ctx, lib.rt_render(ctx, C.byref(cam), C.byref(L), C.byref(p), rgb.ctypes.data_as(C.c_void_p), None, None), "work: rt_render")
+        buf = (C.c_uint64 * 768)()
+        capi.check(lib, ctx, lib.rt_debug_work_counters(ctx, buf, 768), "rt_debug_work_counters")
+        a = [int(x) for x in buf]
+    finally:
+        lib.rt_destroy(ctx)
+    s = a[RT_WORK_SHADOW:RT_WORK_SHADOW + 96]
+    t = a[0:96]
+    names = {0: "tri_steps_lanes_rays", 2: "tri_steps_lanes_triangles", 4: "box_steps_stack_walk", 12: "chunk_tests_stack_walk", 13: "units",
+             88: "shaft_groups", 90: "nodes_tested_per_ray", 91: "nodes_hit", 92: "leaf_chunk_batches", 94: "chunks_tested_per_ray", 95: "chunks_with_work"}
+    return {"shadow": {v: s[k] for k, v in names.items()}, "trace": {v: t[k] for k, v in names.items()}}
+
+
+def valu_model(work, flat, shaft):
+    """modelled VALU wave-instructions of the shadow kernels of the frame: (useful, total)"""
+    w = work["shadow"]
+    useful = w["tri_steps_lanes_triangles"] * COST["tri_lanes_triangles"] + w["tri_steps_lanes_rays"] * COST["tri_lanes_rays"]
+    if flat:
+        return useful, useful + w["units"] * COST["unit_flat"]
+    if shaft:
+        useful += w["nodes_tested_per_ray"] * COST["node_per_ray"]
+        total = useful + w["units"] * COST["unit_shaft"] + w["shaft_groups"] * COST["shaft_group"] + w["leaf_chunk_batches"] * COST["leaf_chunk_batch"] + \
+            w["chunks_tested_per_ray"] * COST["chunk_per_ray"]
+        # leaf tasks handed to the stack-walk launch (k_shadow<.., CONT>) report their chunk tests / triangle steps through the same counters
+        total += w["chunk_tests_stack_walk"] * 30
+        return useful, total
+    useful += w["box_steps_stack_walk"] * COST["box_stack_walk"]
+    return useful, useful + w["units"] * COST["unit_stack"] + w["chunk_tests_stack_walk"] * 30
+
+
+def pmc_constant(fname, scene, cfg, sha):
+    """an entry of profiles/valu.json / traffic.json, only while it was taken with the kernels source that is being timed"""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        ent = j.get(scene)
+        if not ent or ent.get("config") != cfg:
+            return None, "no entry for this workload"
+        if ent.get("kernels_sha256") != sha:
+            return None, "profiles/%s was collected with a different rt_kernels.hip (stale): not quoted" % fname
+        return ent, None
+    except Exception as e:       # noqa: BLE001
+        return None, str(e)
+
+
+def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, cpu_stride, want_graph, want_work=True):
+    """N = 1: eager launches with per-kernel HIP events on every 4th step; returns the record of this workload"""
+    import numpy as np
+    capi = pkg.capi
+    scene_file, scene_path = scene_of(scene)
+    hs = pkg.HostScene(scene_path, 1000, 15)
+    ctx = pkg.Context(dev.index)
+    ctx.upload(hs)
+    lib = ctx.lib
+    cam = pkg.default_camera(W, H)
+    L = pkg.make_lights(area=True, usteps=G, vsteps=G)
+    out_rgb = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+    out_u8 = torch.zeros(H * W * 3, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def _p(collect):
+        p = pkg.make_params(W, H, D, 0, H, S, 0, 1)
+        p.collect_stats = collect
+        return p
+
+    def render(p, stats=None):
+        st = lib.rt_render_device(ctx.handle, C.byref(cam), C.byref(L), C.byref(p), C.c_void_p(out_rgb.data_ptr()), C.c_void_p(out_u8.data_ptr()), None,
+                                  C.c_void_p(stream.cuda_stream), C.byref(stats) if stats is not None else None)
+        capi.check(lib, ctx.handle, st, "rt_render_device")
+
+    # untimed: algorithmic counters (no-early-out counting variants)
+    cnt = capi.rt_stats()
+    render(_p(1), cnt)
+    torch.cuda.synchronize(dev)
+    rays_frame = cnt.total_rays()
+    p_timed, p_plain = _p(2), _p(0)
+    for _ in range(warmup):
+        render(p_timed)
+    torch.cuda.synchronize(dev)
+    lib.rt_timing_collect(ctx.handle, C.byref(capi.rt_stats()))
+    # ---- timed region: EXACTLY K steps between synchronisations
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        render(p_timed if i % 4 == 0 else p_plain)      # per-kernel HIP events on every 4th step (the ~17 event records cost ~60 us)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    tim = capi.rt_stats()
+    capi.check(lib, ctx.handle, lib.rt_timing_collect(ctx.handle, C.byref(tim)), "rt_timing_collect")
+    brk = capi.rt_stats()
+    render(_p(0), brk)                                   # untimed: an event between every pair of launches
+    torch.cuda.synchronize(dev)
+    K_t = (steps + 3) // 4
+    ms_step = elapsed / steps * 1e3
+    value = rays_frame * steps / elapsed / 1e6
+    launches = max(1, tim.launches_shadow)
+    launches_per_frame = launches / K_t
+    ms_shadow_frame = tim.ms_shadow / K_t
+    avg_ms_shadow = tim.ms_shadow / launches
+    cfg = f"{W}x{H} depth {D} {G * G} samples"
+    sha = kernels_sha()
+    info = hs.info()
+    flat = info["nodes"] == 1
+    shaft = (not flat) and G * G > 32 and not os.environ.get("RT_NO_SHAFT") and not os.environ.get("RT_NO_CULL")
+
+    # ---- executed work of this frame -> modelled VALU issue
+    work = work_counters(pkg, hs, W, H, G, D) if want_work else None
+    roof = {"bound": "valu", "kernel": "k_shadow (area-light sample shadow rays" + ("; shaft walk + leaf-task launch)" if shaft else ")"),
+            "unit": "wave-instructions/SIMD/ns", "peak": VALU_PEAK_PER_SIMD_NS,
+            "peak_source": "tools/micro/valu_rate.hip on MI355X: plain FP32 wave64 ops, 8 waves/SIMD (spec: 0.5/cycle = 1.2/ns at 2.4 GHz)"}
+    if work:
+        useful, total = valu_model(work, flat, shaft)
+        t_ns = ms_shadow_frame * 1e6
+        roof["achieved"] = round(total / t_ns / N_SIMDS, 4)
+        roof["frac"] = round(total / t_ns / N_SIMDS / VALU_PEAK_PER_SIMD_NS, 4)
+        roof["useful_frac"] = round(useful / t_ns / N_SIMDS / VALU_PEAK_PER_SIMD_NS, 4)
+        roof["modelled_valu_wave_instructions_per_frame"] = {"useful": int(useful), "total": int(total)}
+        roof["work"] = work
+        roof["cost_per_step"] = COST
+    else:
+        roof.update({"achieved": None, "frac": None, "note": "no counting pass (--no-work-counters, or librt_mi355x_work.so missing: run __graft_entry__.build())"})
+    ent, why = pmc_constant("valu.json", scene, cfg, sha)
+    if ent:
+        insts = sum(v["valu_wave_instructions"] for k, v in ent["kernels"].items() if "k_shadow" in k)
+        r = insts / (ms_shadow_frame * 1e6) / N_SIMDS
+        roof["executed_valu"] = {"constant": True, "wave_instructions_per_frame_level0": int(insts), "per_simd_per_ns": round(r, 4),
+                                 "frac": round(r / VALU_PEAK_PER_SIMD_NS, 4), "source": ent["how"]}
+    else:
+        roof["executed_valu"] = {"constant": True, "frac": None, "why": why}
+    ent, why = pmc_constant("traffic.json", scene, cfg, sha)
+    if ent:
+        roof["traffic"] = ent["hbm_bytes_per_launch"]
+        roof["hbm_frac"] = round(ent["hbm_bytes_per_launch"] / (avg_ms_shadow * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        roof["traffic_source"] = "constant: " + ent["how"]
+    else:
+        roof["traffic"] = None
+        roof["hbm_frac"] = None
+        roof["traffic_source"] = why
+    alg = BOX_BYTES * cnt.box_tests_shadow + TRI_REF_BYTES * cnt.leaf_tri_refs_shadow
+    roof["reference_semantics_bytes"] = {"per_frame_k_shadow": int(alg), "GBs_over_launch_time": round(alg / (ms_shadow_frame * 1e-3) / 1e9, 1),
+                                         "note": "SURVEY 8(d) algorithmic bytes (no early-out, no culling); a workload size, NOT a utilisation: above the HBM peak by construction"}
+    roof["avg_launch_ms"] = round(avg_ms_shadow, 5)
+    roof["launches_per_frame"] = launches_per_frame
+    roof["timing_source"] = f"HIP events on the launch stream inside the timed region (every 4th step: {K_t} of {steps} frames)"
+    roof["ms_per_frame"] = {"shadow": round(ms_shadow_frame, 4), "device_total": round(tim.ms_total / K_t, 4),
+                            "instrumented_frame": {"trace": round(brk.ms_trace, 4), "shadow": round(brk.ms_shadow, 4), "shade": round(brk.ms_shade, 4),
+                                                   "resolve": round(brk.ms_resolve, 4), "total": round(brk.ms_total, 4)}}
+
+    rec = {"value": round(value, 2), "ms_per_step": round(ms_step, 4), "steps": steps, "warmup": warmup, "rays_per_frame": rays_frame,
+           "config": {"workload": f"{W}x{H} depth {D} {G * G}-sample area light, {scene_file}, 1 light, row stripes of {S} over 1 GPU(s)",
+                      "width": W, "height": H, "max_depth": D, "samples": G * G, "scene": scene_file, "parallelism": "rows1", "step": "eager launches",
+                      "tree": {k: info[k] for k in ("nodes", "leaves", "face_refs", "max_leaf", "depth")}},
+           "rays": {"primary": cnt.rays_primary, "centre": cnt.rays_centre, "sample": cnt.rays_sample, "bounce": cnt.rays_bounce, "culled_pixels": cnt.pixels_culled},
+           "roofline": roof}
+
+    if want_graph:
+        # extra (untimed for `value`): K frames replayed from ONE captured hipGraph, camera yaw stepping 2*pi/120 per frame (BASELINE cfg5)
+        try:
+            g = pkg.FrameGraph(ctx, L, _p(0), out_rgb.data_ptr(), out_u8.data_ptr())
+            cams = [pkg.default_camera(W, H, float(np.float32(2.0 * np.pi * f / 120.0))) for f in range(min(steps, 120))]
+            g.launch(cams[0], stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            tg0 = time.perf_counter()
+            for cm in cams:
+                g.launch(cm, stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            rec["graph_replay_ms_per_frame_yaw_path"] = round((time.perf_counter() - tg0) / len(cams) * 1e3, 4)
+            tg0 = time.perf_counter()
+            for _ in cams:
+                g.launch(cam, stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            rec["graph_replay_ms_per_frame_same_camera"] = round((time.perf_counter() - tg0) / len(cams) * 1e3, 4)
+            g.close()
+        except Exception as e:            # noqa: BLE001 -- the graph path is an extra; never let it take the bench line down
+            rec["graph_replay_ms_per_frame_yaw_path"] = f"failed: {e}"
+
+    if want_cpu:
+        # CPU baseline beside it: the oracle (a port of the reference's algorithm) on this host's cores, bounded sample of the same workload
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        orc = oracle_lib.load()
+        osc = orc.load_scene(scene_path)
+        threads = max(1, min(16, os.cpu_count() or 2) - 1)     # the reference uses hardware_concurrency()-1 (flyscene.cpp:558); a 1-GPU box's share is 16 cores
+        stride = cpu_stride or (8 if scene == "wavy" else (2 if scene == "dodge" else 1))
+        n = 0; sec = 0.0; cpu_rays = 0; reps = 0
+        while reps == 0 or (sec * threads < 10.0 and reps < 64):
+            n1, s1, ost = osc.render_subsample(orc.camera(W, H), orc.lights(area=True, usteps=G, vsteps=G), W, H, stride, max_depth=D, threads=threads)
+            n += n1; sec += s1; cpu_rays += ost.total_rays(); reps += 1
+        rec["cpu_baseline"] = {
+            "value": round(cpu_rays / sec / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} x every {stride}th pixel in x and y of the same {W}x{H} frame ({n} pixels, {cpu_rays} rays) in {sec:.2f} s on {threads} threads "
+                      f"= {sec * threads:.0f} s of CPU work; oracle/rt_oracle.c (C restatement, no per-node deep copies) -- NOT the unmodified reference, "
+                      "which measured 0.165-2.6 Mrays/s on 7 threads (BASELINE.md)",
+            "seconds": round(sec, 3)}
+        rec["speedup_vs_cpu_port"] = round(value / (cpu_rays / sec / 1e6), 1)
+        osc.close()
+    ctx.close()
+    hs.close()
+    return rec
+
+
+def run_multi(pkg, torch, dist, dev, rank, world, backend, args):
+    """N > 1: every rank renders its interleaved row stripes; the step is a hipGraph replay of the frame + ONE gather of the 8-bit rows to
+    rank 0 through the library's own RCCL binding (rt_comm_gather_rows), double buffered so that render i+1 overlaps gather i."""
+    import numpy as np
+    capi = pkg.capi
+    on_host = backend != "nccl"
+    scene_file, scene_path = scene_of(args.scene)
+    W, H, G, D, S = args.width, args.height, args.grid, args.depth, args.stripe
+    hs = pkg.HostScene(scene_path, 1000, 15)
+    ctx = pkg.Context(dev.index)
+    ctx.upload(hs)
+    lib = ctx.lib
+    cam = pkg.default_camera(W, H)
+    L = pkg.make_lights(area=True, usteps=G, vsteps=G)
+    max_rows = pkg.shard.max_local_rows(H, S, world)
+    block = max_rows * W * 3
+    out_rgb = torch.zeros(block, dtype=torch.float32, device=dev)
+    u8 = [torch.zeros(block, dtype=torch.uint8, device=dev) for _ in range(2)]
+    gathered = [torch.zeros(block * world, dtype=torch.uint8, device=dev) if rank == 0 else None for _ in range(2)]
+    stream = torch.cuda.current_stream(dev)
+
+    def _p(collect):
+        p = pkg.make_params(W, H, D, 0, H, S, rank, world)
+        p.collect_stats = collect
+        return p
+
+    def reduce_(t, op):
+        if on_host:
+            c = t.cpu(); dist.all_reduce(c, op=op); t.copy_(c)
+        else:
+            dist.all_reduce(t, op=op)
+
+    def render_eager(buf, p, stats=None):
+        st = lib.rt_render_device(ctx.handle, C.byref(cam), C.byref(L), C.byref(p), C.c_void_p(out_rgb.data_ptr()), C.c_void_p(buf.data_ptr()), None,
+                                  C.c_void_p(stream.cuda_stream), C.byref(stats) if stats is not None else None)
+        capi.check(lib, ctx.handle, st, "rt_render_device")
+
+    cnt = capi.rt_stats()
+    render_eager(u8[0], _p(1), cnt)
+    torch.cuda.synchronize(dev)
+    counters = torch.tensor([cnt.total_rays(), cnt.rays_primary, cnt.rays_centre, cnt.rays_sample, cnt.rays_bounce, cnt.pixels_culled], dtype=torch.float64, device=dev)
+    reduce_(counters, dist.ReduceOp.SUM)
+    tot = [int(x) for x in counters.tolist()]
+
+    # ---- the library's own communicator (RCCL, one per process/GPU); the unique id travels over torch.distributed
+    comm, step_kind = None, None
+    if not on_host and not args.eager:
+        try:
+            idt = torch.zeros(capi.RT_COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(pkg.shard.Comm.unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, src=0)
+            comm = pkg.shard.Comm(dev.index, bytes(idt.cpu().numpy().tobytes()), world, rank)
+        except Exception as e:            # noqa: BLE001
+            print(f"[bench] rt_comm setup failed on rank {rank}: {e}; falling back to torch.distributed.gather", file=sys.stderr)
+            comm = None
+    flag = torch.tensor([1.0 if comm else 0.0], dtype=torch.float64, device=dev)
+    reduce_(flag, dist.ReduceOp.MIN)                    # every rank must take the same path
+    if flag.item() < 0.5 and comm:
+        comm.close(); comm = None
+
+    graphs = None
+    if comm:
+        try:
+            graphs = [pkg.FrameGraph(ctx, L, _p(0), out_rgb.data_ptr(), u8[i].data_ptr()) for i in range(2)]
+        except Exception as e:            # noqa: BLE001
+            print(f"[bench] graph capture failed on rank {rank}: {e}; eager launches", file=sys.stderr)
+            graphs = None
+    gstream = torch.cuda.Stream(device=dev) if comm else None
+    rendered = [torch.cuda.Event() for _ in range(2)]
+    gathered_ev = [torch.cuda.Event() for _ in range(2)]
+
+    def step_comm(i):
+        b = i & 1
+        if i >= 2:
+            stream.wait_event(gathered_ev[b])            # buffer b was read by gather i-2
+        if graphs:
+            graphs[b].launch(cam, stream.cuda_stream)
+        else:
+            render_eager(u8[b], _p(0))
+        rendered[b].record(stream)
+        gstream.wait_event(rendered[b])
+        comm.gather_rows(u8[b].data_ptr(), block, gathered[b].data_ptr() if rank == 0 else 0, 0, gstream.cuda_stream)
+        gathered_ev[b].record(gstream)
+
+    def step_torch(i):
+        render_eager(u8[0], _p(0))
+        src = u8[0].cpu() if on_host else u8[0]
+        bufs = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
+        dist.gather(src, gather_list=bufs, dst=0)
+
+    step = step_comm if comm else step_torch
+    step_kind = ("hipGraph replay" if graphs else "eager launches") + " + rt_comm_gather_rows (RCCL via the C ABI), double buffered" if comm \
+        else "eager launches + torch.distributed.gather"
+    for i in range(max(4, args.warmup)):
+        step(i)
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    t1 = time.perf_counter()
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    reduce_(el, dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    # untimed: one instrumented eager frame for the per-kernel breakdown of rank 0's rows
+    brk = capi.rt_stats()
+    render_eager(u8[0], _p(0), brk)
+    torch.cuda.synchronize(dev)
+    check = None
+    if rank == 0 and comm:
+        full = pkg.shard.stitch_u8(gathered[(args.steps - 1) & 1].cpu().numpy(), block, W, H, S, world)
+        check = {"assembled_frame_sha256": hashlib.sha256(full.tobytes()).hexdigest(), "nonzero": bool(full.any())}
+    if comm:
+        comm.close()
+    if rank != 0:
+        return None
+    K = args.steps
+    return {"value": round(tot[0] * K / elapsed / 1e6, 2), "ms_per_step": round(elapsed / K * 1e3, 4), "steps": K, "warmup": args.warmup, "rays_per_frame": tot[0],
+            "config": {"workload": f"{W}x{H} depth {D} {G * G}-sample area light, {scene_file}, 1 light, row stripes of {S} over {world} GPU(s)",
+                       "width": W, "height": H, "max_depth": D, "samples": G * G, "scene": scene_file, "parallelism": f"rows{world}", "step": step_kind},
+            "rays": {"primary": tot[1], "centre": tot[2], "sample": tot[3], "bounce": tot[4], "culled_pixels": tot[5]},
+            "gathered_frame": check,
+            "roofline": {"bound": "valu", "kernel": "k_shadow", "achieved": None, "peak": VALU_PEAK_PER_SIMD_NS, "unit": "wave-instructions/SIMD/ns", "frac": None,
+                         "traffic": None, "note": "the executed-work roofline is reported by the N = 1 run (same kernels, 1/N of the rows per rank)",
+                         "timing_source": "one instrumented eager frame of rank 0 outside the timed region (HIP events)",
+                         "ms_per_frame": {"instrumented_frame_rank0": {"trace": round(brk.ms_trace, 4), "shadow": round(brk.ms_shadow, 4),
+                                                                       "shade": round(brk.ms_shade, 4), "resolve": round(brk.ms_resolve, 4), "total": round(brk.ms_total, 4)}}}}
 
 
 def main():
@@ -38,339 +440,59 @@ def main():
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--stripe", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager", action="store_true", help="N > 1: eager launches + synchronous gather instead of graph replay + pipelined gather")
+    ap.add_argument("--no-tree-scenes", action="store_true", help="N = 1: skip the dodge / cfg4 sub-records")
+    ap.add_argument("--no-work-counters", action="store_true", help="skip the counting-build pass (PMC / rocprof runs: its launches carry the same kernel names)")
+    ap.add_argument("--eager", action="store_true", help="N > 1: eager launches + torch.distributed.gather instead of graph replay + rt_comm gather")
     ap.add_argument("--cpu-stride", type=int, default=0, help="oracle pixel stride for the CPU baseline (0 = auto)")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import rtpkg
     pkg = rtpkg.load()
-    capi = pkg.capi
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    dist = None
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ray-trace path has no CPU fallback")
     # RT_DIST_BACKEND=gloo rehearses the N > 1 path on a ONE-GPU box: every rank renders its stripes on GPU 0 and the
-    # gather runs over gloo on host copies.  The real path (default) is one rank per GPU with RCCL ("nccl").
+    # gather runs over gloo on host copies.  The real path (default) is one rank per GPU with RCCL.
     backend = os.environ.get("RT_DIST_BACKEND", "nccl")
     gpu_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(gpu_index)
     dev = torch.device("cuda", gpu_index)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    on_host = world > 1 and backend != "nccl"       # collectives on CPU tensors (rehearsal only)
 
-    if args.scene == "wavy":
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import scenes_gen
-        import tempfile
-        scene_file = "wavy708.obj (synthetic 708x708 displaced grid + floor, 1,002,530 triangles)"
-        scene_path = scenes_gen.wavy_grid(os.path.join(tempfile.gettempdir(), f"rt_wavy_{os.getpid()}"), n=708)
-    else:
-        scene_file = {"cube": "cube.obj", "dodge": "dodgeColorTest.obj"}[args.scene]
-        scene_path = os.path.join(ROOT, "tests", "golden", "scenes", scene_file)
-    W, H, G, D, S = args.width, args.height, args.grid, args.depth, args.stripe
-
-    hs = pkg.HostScene(scene_path, 1000, 15)
-    ctx = pkg.Context(gpu_index)
-    ctx.upload(hs)
-    lib = ctx.lib
-    cam = pkg.default_camera(W, H)
-    L = pkg.make_lights(area=True, usteps=G, vsteps=G)
-    max_rows = pkg.shard.max_local_rows(H, S, world)
-    my_rows = pkg.shard.rows_of_rank(H, S, rank, world)
-    out_rgb = torch.zeros(max_rows * W * 3, dtype=torch.float32, device=dev)
-    out_u8 = torch.zeros(max_rows * W * 3, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream(dev)
-
-    def params(collect):
-        return pkg.make_params(W, H, D, 0, H, S, rank, world, collect_stats=False) if collect == 0 else _p(collect)
-
-    def _p(collect):
-        p = pkg.make_params(W, H, D, 0, H, S, rank, world)
-        p.collect_stats = collect
-        return p
-
-    def render(p, stats=None):
-        st = lib.rt_render_device(ctx.handle, C.byref(cam), C.byref(L), C.byref(p), C.c_void_p(out_rgb.data_ptr()),
-                                  C.c_void_p(out_u8.data_ptr()), None, C.c_void_p(stream.cuda_stream),
-                                  C.byref(stats) if stats is not None else None)
-        capi.check(lib, ctx.handle, st, "rt_render_device")
-
-    def gather_rows():
-        src = out_u8.cpu() if on_host else out_u8
-        bufs = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
-        dist.gather(src, gather_list=bufs, dst=0)         # the single RCCL exchange of the frame
-        return bufs
-
-    def reduce_(t, op):
-        if on_host:
-            c = t.cpu()
-            dist.all_reduce(c, op=op)
-            t.copy_(c)
-        else:
-            dist.all_reduce(t, op=op)
-
-    def step(p):
-        render(p)
-        if world > 1:
-            return gather_rows()
-        return None
-
-    # ---- untimed: algorithmic counters of this rank's rows (no-early-out counting variants) ----------------
-    cnt = capi.rt_stats()
-    render(_p(1), cnt)
-    torch.cuda.synchronize(dev)
-    rays_local = cnt.total_rays()
-    counters = torch.tensor([rays_local, cnt.box_tests, cnt.leaf_tri_refs, cnt.box_tests_shadow, cnt.leaf_tri_refs_shadow,
-                             cnt.rays_sample, cnt.rays_primary, cnt.rays_centre, cnt.rays_bounce, cnt.pixels_culled],
-                            dtype=torch.float64, device=dev)
-    if world > 1:
-        reduce_(counters, dist.ReduceOp.SUM)
-    tot = [int(x) for x in counters.tolist()]
-    rays_frame = tot[0]
-
-    # ---- N > 1: the per-rank frame is ~1/N of the work, so launch overhead and the gather dominate.  The step is then
-    # a hipGraph REPLAY of the frame (one host call instead of 17 launches) and the gather is asynchronous and
-    # double-buffered: render i+1 overlaps gather i (all K gathers complete inside the timed region).  N = 1 keeps eager
-    # launches with per-kernel HIP events, as the roofline contract asks.
-    pipe = None
-    if world > 1 and not on_host and not args.eager:
-        try:
-            u8 = [out_u8, torch.zeros_like(out_u8)]
-            graphs = [pkg.FrameGraph(ctx, L, _p(0), out_rgb.data_ptr(), u8[i].data_ptr()) for i in range(2)]
-            recv = [[torch.empty_like(out_u8) for _ in range(world)] for _ in range(2)] if rank == 0 else [None, None]
-            pipe = {"u8": u8, "graphs": graphs, "recv": recv, "pending": []}
-        except Exception as e:        # fall back to the synchronous eager step
-            print(f"[bench] graph/pipeline setup failed on rank {rank}: {e}; using the eager step", file=sys.stderr)
-            pipe = None
-
-    def step_pipe(i):
-        b = i & 1
-        pend = pipe["pending"]
-        if len(pend) >= 2:
-            pend[-2].wait()                       # stream-level wait: buffer b was read by gather i-2
-        pipe["graphs"][b].launch(cam, stream.cuda_stream)
-        pend.append(dist.gather(pipe["u8"][b], gather_list=pipe["recv"][b], dst=0, async_op=True))
-
-    def drain_pipe():
-        for h in pipe["pending"]:
-            h.wait()
-        pipe["pending"].clear()
-
-    # ---- warmup ----------------------------------------------------------------------------------------------
-    p_timed = _p(2)           # deferred per-kernel HIP events on the launch stream, no host sync inside the step
-    p_plain = _p(0)
-    if pipe:
-        try:                                      # exercise every pipeline call (incl. the i-2 wait) before the timed region
-            for i in range(max(3, args.warmup)):
-                step_pipe(i)
-            drain_pipe()
-            torch.cuda.synchronize(dev)
-        except Exception as e:
-            print(f"[bench] pipelined step failed on rank {rank}: {e}; using the eager step", file=sys.stderr)
-            pipe = None
-    # every rank must take the same path (the collectives differ): agree on the minimum
-    if world > 1:
-        flag = torch.tensor([1.0 if pipe else 0.0], dtype=torch.float64, device=dev)
-        reduce_(flag, dist.ReduceOp.MIN)
-        if flag.item() < 0.5:
-            pipe = None
-    if not pipe:
-        for i in range(args.warmup):
-            step(p_timed)
-    torch.cuda.synchronize(dev)
-    warm = capi.rt_stats()
-    lib.rt_timing_collect(ctx.handle, C.byref(warm))
-
-    # ---- timed region: EXACTLY K steps between barrier + synchronize ---------------------------------------
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if pipe:
-            step_pipe(i)
-        else:
-            # per-kernel HIP events on every 4th step only: the ~17 event records of a frame cost ~60 us (6 % of the cube frame)
-            step(p_timed if i % 4 == 0 else p_plain)
-    if pipe:
-        drain_pipe()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        reduce_(elapsed, dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
-    tim = capi.rt_stats()
-    capi.check(lib, ctx.handle, lib.rt_timing_collect(ctx.handle, C.byref(tim)), "rt_timing_collect")
-    # untimed: one fully instrumented frame (an event between every pair of launches) for the per-kernel breakdown
-    brk = capi.rt_stats()
-    render(_p(0), brk)
-    torch.cuda.synchronize(dev)
-
-    # ---- extra (untimed for `value`): the same K frames replayed from ONE captured hipGraph, camera yaw stepping
-    # 2*pi/120 per frame (BASELINE cfg5's animation path); reported as graph_replay_ms_per_frame
-    graph_ms = None
-    graph_same_ms = None
-    try:
-        g = pkg.FrameGraph(ctx, L, _p(0), out_rgb.data_ptr(), out_u8.data_ptr())
-        cams = [pkg.default_camera(W, H, float(np.float32(2.0 * np.pi * f / 120.0))) for f in range(args.steps)]
-        g.launch(cams[0], stream.cuda_stream)
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        tg0 = time.perf_counter()
-        for f in range(args.steps):
-            g.launch(cams[f], stream.cuda_stream)
-            if world > 1:
-                gather_rows()
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        graph_ms = (time.perf_counter() - tg0) / args.steps * 1e3
-        tg0 = time.perf_counter()
-        for f in range(args.steps):               # same camera as the timed region: the launch-overhead comparison
-            g.launch(cam, stream.cuda_stream)
-            if world > 1:
-                gather_rows()
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        graph_same_ms = (time.perf_counter() - tg0) / args.steps * 1e3
-        g.close()
-    except Exception as e:            # the graph path is an extra; never let it take the bench line down
-        graph_ms = f"failed: {e}"
-
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+    base = {"metric": "Mrays/s", "unit": "Mrays/s", "n_gpus": world, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic"}
+    if world == 1:
+        default_call = args.scene == "cube" and (args.width, args.height, args.grid, args.depth) == (1920, 1080, 8, 4)
+        rec = run_single(pkg, torch, dev, args.scene, args.width, args.height, args.grid, args.depth, args.stripe, args.steps, args.warmup,
+                         not args.no_cpu_baseline, args.cpu_stride, True, not args.no_work_counters)
+        out = dict(base)
+        out.update(rec)
+        if default_call and not args.no_tree_scenes:
+            # the octree traversal the north star is about is NOT in the cube headline (1-node tree): time it here, same invocation
+            out["tree_scenes"] = {
+                "dodge_1920x1080_d4_s64": run_single(pkg, torch, dev, "dodge", 1920, 1080, 8, 4, args.stripe, min(args.steps, 100), min(args.warmup, 5),
+                                                     not args.no_cpu_baseline, 0, False),
+                "cfg4_wavy_3840x2160_d8_s256": run_single(pkg, torch, dev, "wavy", 3840, 2160, 16, 8, args.stripe, 5, 2, not args.no_cpu_baseline, 0, False)}
+        print(json.dumps(out), flush=True)
         return
 
-    K = args.steps
-    ms_step = elapsed / K * 1e3
-    value = rays_frame * K / elapsed / 1e6
-    # roofline of the dominant kernel (k_shadow: area-light sample shadow rays), rank 0's launches.
-    # achieved = algorithmic bytes per launch / average launch duration (HIP events on the launch stream).
-    timing_source = "HIP events on the launch stream inside the timed region"
-    if tim.launches_shadow == 0:          # graph replay (N > 1): no per-kernel events inside the timed region
-        tim = brk
-        timing_source = "one instrumented eager frame outside the timed region (the timed loop replays a hipGraph)"
-        K_t = 1
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
     else:
-        K_t = (K + 3) // 4                # frames of the timed region that carried events (every 4th)
-        timing_source += f" (every 4th step: {K_t} of {K} frames)"
-    launches = max(1, tim.launches_shadow)
-    avg_ms_shadow = tim.ms_shadow / launches
-    alg_shadow_frame = BOX_BYTES * cnt.box_tests_shadow + TRI_REF_BYTES * cnt.leaf_tri_refs_shadow   # rank 0's rows
-    launches_per_frame = launches / K_t
-    alg_per_launch = alg_shadow_frame / launches_per_frame
-    achieved = alg_per_launch / (avg_ms_shadow * 1e-3) / 1e9 if avg_ms_shadow > 0 else 0.0
-    trace_alg = BOX_BYTES * (cnt.box_tests - cnt.box_tests_shadow) + TRI_REF_BYTES * (cnt.leaf_tri_refs - cnt.leaf_tri_refs_shadow)
-    trace_gbs = trace_alg / (brk.ms_trace * 1e-3) / 1e9 if brk.ms_trace > 0 else 0.0
-    # HBM traffic of the dominant kernel from the PMC counters (separate rocprofv3 --pmc passes, profiles/traffic.json);
-    # only quoted when the committed measurement is for this very workload
-    traffic = None
-    traffic_note = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        ent = tj.get(args.scene)
-        if ent and ent["config"] == f"{W}x{H} depth {D} {G * G} samples" and world == 1:
-            traffic = ent["hbm_bytes_per_launch"]
-            traffic_note = ent["how"]
-    except Exception:
-        pass
-    # What actually bounds the kernel: VALU issue.  Wave-instructions of the level-0 launch from the committed PMC pass
-    # (profiles/valu.json, tools/valu.sh) over this run's live launch time, against the plain-FP32 issue rate measured on this
-    # chip by tools/micro/valu_rate.hip (0.967 wave-instructions per SIMD per ns = one wave64 v_mul/v_add/v_fma every 2 cycles;
-    # v_cmp ~3, v_readlane/v_div_* ~4, v_rcp ~8 cycles: the kernel's own mix cannot reach 1.0).
-    valu = None
-    try:
-        vj = json.load(open(os.path.join(ROOT, "profiles", "valu.json")))
-        ent = vj.get(args.scene)
-        if ent and ent["config"] == f"{W}x{H} depth {D} {G * G} samples" and world == 1:
-            ks = {k: v for k, v in ent["kernels"].items() if "k_shadow" in k}
-            insts = sum(v["valu_wave_instructions"] for v in ks.values())
-            t_s = (tim.ms_shadow / K_t) * 1e-3        # all k_shadow launches of a frame (level 0 dominates; leaf-task launch included)
-            rate = insts / t_s / 1e9 / 1024.0 if t_s > 0 else 0.0
-            valu = {"wave_instructions_per_frame_level0": int(insts), "achieved_per_simd_per_ns": round(rate, 4),
-                    "peak_per_simd_per_ns": VALU_PEAK_PER_SIMD_NS, "frac": round(rate / VALU_PEAK_PER_SIMD_NS, 4),
-                    "source": ent["how"]}
-    except Exception:
-        pass
-    roofline = {
-        "bound": "hbm", "kernel": "k_shadow", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
-        "algorithmic_bytes_per_launch": int(alg_per_launch), "avg_launch_ms": round(avg_ms_shadow, 5),
-        "launches_per_frame": launches_per_frame,
-        "note": "algorithmic bytes = 24 B x box tests + 52 B x leaf triangle refs in reference semantics (every triangle of every "
-                "intersected leaf, no early-out: SURVEY 8d); the kernel skips most of that work exactly (culling) and the scene is "
-                "cache resident, so this is neither HBM traffic nor bounded by the HBM peak -- valu_issue is the real bound (DESIGN.md 5)",
-        "valu_issue": valu,
-        "k_trace": {"achieved": round(trace_gbs, 1), "ms_per_frame": round(brk.ms_trace, 4)},
-        "timing_source": timing_source,
-        "ms_per_frame": {"shadow": round(tim.ms_shadow / K_t, 4), "device_total": round(tim.ms_total / K_t, 4),
-                         "instrumented_frame": {"trace": round(brk.ms_trace, 4), "shadow": round(brk.ms_shadow, 4),
-                                                "shade": round(brk.ms_shade, 4), "resolve": round(brk.ms_resolve, 4),
-                                                "total": round(brk.ms_total, 4)}},
-    }
-
-    out = {
-        "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{W}x{H} depth {D} {G * G}-sample area light, {scene_file}, "
-                               f"1 light, row stripes of {S} over {world} GPU(s)",
-                   "width": W, "height": H, "max_depth": D, "samples": G * G, "scene": scene_file,
-                   "parallelism": f"rows{world}", "step": ("hipGraph replay + pipelined RCCL gather" if pipe else ("eager launches" + (" + gather" if world > 1 else "")))},
-        "rays_per_frame": rays_frame,
-        "graph_replay_ms_per_frame_120_frame_yaw_path": (round(graph_ms, 4) if isinstance(graph_ms, float) else graph_ms),
-        "graph_replay_ms_per_frame_same_camera": (round(graph_same_ms, 4) if isinstance(graph_same_ms, float) else graph_same_ms),
-        "rays": {"primary": tot[6], "centre": tot[7], "sample": tot[5], "bounce": tot[8], "culled_pixels": tot[9]},
-        "roofline": roofline,
-    }
-
-    # ---- CPU baseline beside it: the oracle (a port of the reference's algorithm), rank 0, N = 1 only ------
-    if world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib
-        orc = oracle_lib.load()
-        osc = orc.load_scene(scene_path)
-        # the reference uses hardware_concurrency()-1 threads (flyscene.cpp:558); a 1-GPU box's CPU share is 16 cores
-        threads = max(1, min(16, os.cpu_count() or 2) - 1)
-        stride = args.cpu_stride or (8 if args.scene == "wavy" else 1)     # cfg4's whole 4K frame takes the oracle minutes: 1/64 of the pixels
-        # whole frames of the same workload, repeated until ~10 s of CPU work (threads x wall) have been timed
-        n = 0; sec = 0.0; cpu_rays = 0; reps = 0
-        while reps == 0 or (sec * threads < 10.0 and reps < 64):
-            n1, s1, ost = osc.render_subsample(orc.camera(W, H), orc.lights(area=True, usteps=G, vsteps=G), W, H, stride, max_depth=D, threads=threads)
-            n += n1; sec += s1; cpu_rays += ost.total_rays(); reps += 1
-        out["cpu_baseline"] = {
-            "value": round(cpu_rays / sec / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x every {stride}th pixel in x and y of the same {W}x{H} frame ({n} pixels, {cpu_rays} rays) in {sec:.2f} s "
-                      f"on {threads} threads = {sec * threads:.0f} s of CPU work; "
-                      "oracle/rt_oracle.c (C restatement, no per-node deep copies) -- NOT the unmodified reference, which "
-                      "measured 0.165-2.6 Mrays/s on 7 threads (BASELINE.md)",
-            "seconds": round(sec, 3),
-        }
-        out["speedup_vs_cpu_port"] = round(value / (cpu_rays / sec / 1e6), 1)
-        osc.close()
-    print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    rec = run_multi(pkg, torch, dist, dev, rank, world, backend, args)
+    if rank == 0:
+        out = dict(base)
+        out.update(rec)
+        print(json.dumps(out), flush=True)
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -20,6 +20,7 @@
 #ifndef RT_MI355X_H
 #define RT_MI355X_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -127,6 +128,7 @@ rt_status   rt_create(rt_ctx **out, int device);                     /* replaces
 void        rt_destroy(rt_ctx *ctx);                                 /* replaces: pool.~ThreadPool() flyscene.cpp:634 */
 const char *rt_last_error(const rt_ctx *ctx);                        /* NULL-safe; static string when ctx == NULL     */
 const char *rt_version(void);
+void       *rt_stream(rt_ctx *ctx);                                  /* the context's own hipStream_t (what a NULL `stream` argument means)   */
 
 /* replaces: the scene state traceRay reads through `this` (octree, mesh, materials).  Arrays are copied.          */
 rt_status rt_upload_scene(rt_ctx *ctx, const rt_scene *scene);
@@ -159,6 +161,29 @@ rt_status rt_graph_launch(rt_graph *g, const rt_camera *cam, void *stream);
 /* synchronises and returns the ray counters of the last replayed frame                                             */
 rt_status rt_graph_stats(rt_graph *g, rt_stats *out);
 void      rt_graph_destroy(rt_graph *g);
+
+/* ---- multi-GPU: one process per GPU, row stripes (rt_params.stripe / rank / nranks), ONE RCCL gather over xGMI -----------------------
+ * No reference counterpart (single process, std::thread pool: src/flyscene.cpp:558-629).  RCCL is bound at run time (dlopen); a
+ * single-GPU user never loads it.  Typical use on every rank:
+ *     rank 0: rt_comm_unique_id(id); broadcast id to the other processes out of band (MPI, a file, torch.distributed ...)
+ *     rt_comm_create(&comm, device, id, nranks, rank);
+ *     per frame: rt_render_gather(ctx, comm, &cam, &lights, &params, d_local_u8, block_bytes, d_gathered_u8 /-root only-/, 0, stream);
+ *     root: copy d_gathered_u8 to the host, rt_stitch_rows(...), rt_write_ppm_u8("result.ppm", ...)                                    */
+#define RT_COMM_ID_BYTES 128          /* sizeof(ncclUniqueId) */
+typedef struct rt_comm rt_comm;
+rt_status   rt_comm_unique_id(uint8_t id[RT_COMM_ID_BYTES]);
+rt_status   rt_comm_create(rt_comm **out, int device, const uint8_t id[RT_COMM_ID_BYTES], int32_t nranks, int32_t rank);
+void        rt_comm_destroy(rt_comm *comm);
+const char *rt_comm_last_error(const rt_comm *comm);
+/* the single exchange of a frame: `bytes` bytes from every rank to `root` (rank r's block at d_gathered + r * bytes); asynchronous on
+ * `stream` (hipStream_t), no host synchronisation, capturable                                                                       */
+rt_status   rt_comm_gather_rows(rt_comm *comm, const void *d_local, size_t bytes, void *d_gathered, int32_t root, void *stream);
+/* rt_render_device(d_out_u8 = d_local_u8) + rt_comm_gather_rows on the same stream; local_bytes = the common block size
+ * (>= rt_local_rows(p) * width * 3 on every rank)                                                                                   */
+rt_status   rt_render_gather(rt_ctx *ctx, rt_comm *comm, const rt_camera *cam, const rt_lights *lights, const rt_params *p, uint8_t *d_local_u8,
+                             size_t local_bytes, uint8_t *d_gathered_u8, int32_t root, void *stream);
+/* root, host side: de-interleaves the gathered blocks (row0 = 0, row1 = height) into frame[height][width][3]                          */
+rt_status   rt_stitch_rows(const uint8_t *gathered, size_t block_bytes, int32_t width, int32_t height, int32_t stripe, int32_t nranks, uint8_t *frame);
 
 /* number of rows rt_render produces for p */
 int32_t rt_local_rows(const rt_params *p);
@@ -199,6 +224,11 @@ rt_status rt_host_scene_info(const rt_host_scene *hs, int32_t out[8], float root
 
 /* diagnostic, host only: {chunks, cullable chunks, leaves, max chunks per leaf} of the lanes=triangles chunk bounds   */
 rt_status rt_debug_chunk_stats(const rt_scene *scene, int32_t out[4]);
+
+/* diagnostic: wave-level step counters of the last frame, as executed by the shipped kernels (box-test steps, shaft steps, (ray, chunk)
+ * triangle steps ...; layout in DESIGN.md 6).  Only the counting build librt_mi355x_work.so (same sources, -DRT_PROFILE_STEPS) fills them;
+ * the product library returns RT_ERR_UNSUPPORTED.  bench.py uses it, outside the timed region, for the executed-work roofline.          */
+rt_status rt_debug_work_counters(rt_ctx *ctx, uint64_t *out, int32_t n);
 
 /* replaces: Flycamera defaults + setPerspectiveMatrix/setViewport (flyscene.cpp:46-47, flycamera.hpp:76-86)       */
 void rt_default_camera(rt_camera *cam, int32_t width, int32_t height);

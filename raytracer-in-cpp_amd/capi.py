@@ -10,6 +10,7 @@ import os
 RT_OK = 0
 RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_IO, RT_ERR_UNSUPPORTED, RT_ERR_NO_SCENE = -1, -2, -3, -4, -5, -6
 RT_MAX_LIGHTS = 25
+RT_COMM_ID_BYTES = 128
 RT_LIGHT_POINT, RT_LIGHT_AREA = 0, 1
 RT_NODE_LEAF = 0x80000000
 
@@ -75,6 +76,7 @@ _SIGNATURES = [
     ("rt_destroy", None, [C.c_void_p]),
     ("rt_last_error", C.c_char_p, [C.c_void_p]),
     ("rt_version", C.c_char_p, []),
+    ("rt_stream", C.c_void_p, [C.c_void_p]),
     ("rt_upload_scene", C.c_int, [C.c_void_p, _P(rt_scene)]),
     ("rt_render", C.c_int, [C.c_void_p, _P(rt_camera), _P(rt_lights), _P(rt_params), C.c_void_p, C.c_void_p, _P(rt_stats)]),
     ("rt_render_device", C.c_int, [C.c_void_p, _P(rt_camera), _P(rt_lights), _P(rt_params), C.c_void_p, C.c_void_p,
@@ -84,6 +86,14 @@ _SIGNATURES = [
     ("rt_graph_launch", C.c_int, [C.c_void_p, _P(rt_camera), C.c_void_p]),
     ("rt_graph_stats", C.c_int, [C.c_void_p, _P(rt_stats)]),
     ("rt_graph_destroy", None, [C.c_void_p]),
+    ("rt_comm_unique_id", C.c_int, [C.c_void_p]),
+    ("rt_comm_create", C.c_int, [_P(C.c_void_p), C.c_int, C.c_void_p, C.c_int32, C.c_int32]),
+    ("rt_comm_destroy", None, [C.c_void_p]),
+    ("rt_comm_last_error", C.c_char_p, [C.c_void_p]),
+    ("rt_comm_gather_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.c_void_p]),
+    ("rt_render_gather", C.c_int, [C.c_void_p, C.c_void_p, _P(rt_camera), _P(rt_lights), _P(rt_params), C.c_void_p, C.c_size_t, C.c_void_p,
+                                   C.c_int32, C.c_void_p]),
+    ("rt_stitch_rows", C.c_int, [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ("rt_local_rows", C.c_int32, [_P(rt_params)]),
     ("rt_trace_rays", C.c_int, [C.c_void_p, _P(rt_lights), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),
@@ -97,6 +107,7 @@ _SIGNATURES = [
     ("rt_host_scene_set_model", C.c_int, [C.c_void_p, _P(C.c_float), C.c_int32]),
     ("rt_host_scene_info", C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_float)]),
     ("rt_debug_chunk_stats", C.c_int, [_P(rt_scene), _P(C.c_int32)]),
+    ("rt_debug_work_counters", C.c_int, [C.c_void_p, _P(C.c_uint64), C.c_int32]),
     ("rt_default_camera", None, [_P(rt_camera), C.c_int32, C.c_int32]),
     ("rt_yaw_camera", None, [_P(rt_camera), C.c_int32, C.c_int32, C.c_float]),
     ("rt_screen_to_world", None, [_P(rt_camera), C.c_float, C.c_float, _P(C.c_float)]),
@@ -116,6 +127,12 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # PyTorch-ROCm bundles its own libamdhip64 under the same soname as /opt/rocm's.  Whichever is mapped first serves BOTH this library
+    # and torch; when this library came first torch later found "No HIP GPUs".  So: if torch is installed, let it map its runtime first.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # noqa: BLE001 -- torch is plumbing, not a requirement of the C ABI
+        pass
     if not os.path.exists(p):
         raise RuntimeError(
             f"{p} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "

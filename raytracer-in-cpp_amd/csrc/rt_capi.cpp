@@ -36,7 +36,7 @@ void launch_box_probe(hipStream_t st, int n, const float *box, const float *org,
 void launch_tree_probe(int grid, hipStream_t st, const DScene &S, int n, const float *org, const float *dst, uint32_t *out_box, uint32_t *out_ref, uint32_t *out_sig);
 void launch_primary_probe(int grid, hipStream_t st, const DCam *cam, int W, int H, float *out);
 void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow, int *shade);
-void launch_set_prof(hipStream_t st, Control *ctl);
+void launch_set_prof(hipStream_t st, Control *ctl, uint32_t base);
 }  // namespace rtamd
 
 using namespace rtamd;
@@ -112,6 +112,8 @@ static const char *k_no_ctx = "rt_mi355x: null context";
     } while (0)
 
 extern "C" const char *rt_version(void) { return "rt_mi355x 0.1 (gfx950)"; }
+
+extern "C" void *rt_stream(rt_ctx *ctx) { return ctx ? static_cast<void *>(ctx->stream) : nullptr; }
 
 extern "C" const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->err.c_str() : k_no_ctx; }
 
@@ -579,7 +581,7 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
     if (s != RT_OK) return s;
     F.item_cap = F.ray_cap = list_cap(tiles);
     HIPCHK(c, hipMemsetAsync(c->d_ctl, 0, kFrameClearBytes, st));        // everything but the sticky overflow word
-    launch_set_prof(st, c->d_ctl);   // no-op unless built with -DRT_PROFILE
+    launch_set_prof(st, c->d_ctl, 0u);   // no-op unless built with -DRT_PROFILE
     if (!primary) HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->d_ctl->n_rays[0][0]), static_cast<int>(n_input_rays), 1, st));
     size_t ev = c->ev_base;
     if (cam) {   // (skipped when replaying a captured graph)
@@ -614,6 +616,7 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
                          c->d_best, c->d_lit, TaskQueues{nullptr, nullptr, 0u, 0u, cap, 0u});
         }
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
+        launch_set_prof(st, c->d_ctl, RT_WORK_SHADOW);
         // tree scenes with one (hit, light) pair per wave (N > 32 samples): the shaft walk (rt_kernels.hip, k_shadow_shaft)
         const bool shaft = !c->flat && !count && c->S.shaft != 0 && L.n_samples > 32;
         if (shaft)
@@ -626,6 +629,7 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
             launch_shadow_cont(c->cus * c->occ_shadow, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[0], nullptr, 2u, 0u,
                                c->task_cap, 0u);
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));   // after the whole shadow group (incl. continuations)
+        launch_set_prof(st, c->d_ctl, 0u);
         launch_shade(c->cus * c->occ_shade, st, c->S, L, F, level, 3 * level + 2, lslots, c->d_items, c->d_ctl, c->d_vis, rec_l, fres_l, c->d_rays[(level + 1) & 1]);
         if (timed == 1) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
     }
@@ -714,7 +718,7 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
             std::fprintf(stderr, "\n");
         }
         std::fprintf(stderr, "RT_PROFILE shaft walk: groups %llu children %llu shaft-survivors %llu per-ray-survivors %llu | leaf visits %llu chunks %llu shaft-kept %llu with-todo %llu\n",
-                     h.prof[88], h.prof[89], h.prof[90], h.prof[91], h.prof[92], h.prof[93], h.prof[94], h.prof[95]);
+                     h.prof[RT_WORK_SHADOW + 88], h.prof[RT_WORK_SHADOW + 89], h.prof[RT_WORK_SHADOW + 90], h.prof[RT_WORK_SHADOW + 91], h.prof[RT_WORK_SHADOW + 92], h.prof[RT_WORK_SHADOW + 93], h.prof[RT_WORK_SHADOW + 94], h.prof[RT_WORK_SHADOW + 95]);
         std::fprintf(stderr, "RT_PROFILE slowest trace tile %llu: ray-mode leaf triangles %llu, tri-mode leaf triangles %llu, tri-mode (ray,chunk) tests %llu, child boxes %llu\n",
                      h.prof[56], h.prof[57], h.prof[58], h.prof[59], h.prof[60]);
         std::fprintf(stderr, "RT_PROFILE trace tiles: cycles max %llu sum %llu; log2 histogram:", h.prof[38], h.prof[39]);
@@ -1065,6 +1069,22 @@ extern "C" rt_status rt_primary_points(rt_ctx *c, const rt_camera *cam, int32_t 
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, dout.p, nn * 4, hipMemcpyDeviceToHost));
     return RT_OK;
+}
+
+// executed-work counters of the last frame (diagnostic builds only: -DRT_PROFILE -DRT_PROFILE_STEPS, `make work`)
+extern "C" rt_status rt_debug_work_counters(rt_ctx *c, uint64_t *out, int32_t n) {
+    if (!c || !out || n < 0) return RT_ERR_INVALID;
+#if defined(RT_PROFILE) && defined(RT_PROFILE_STEPS)
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t cnt = static_cast<size_t>(n) < sizeof(Control::prof) / sizeof(unsigned long long) ? static_cast<size_t>(n) : sizeof(Control::prof) / sizeof(unsigned long long);
+    HIPCHK(c, hipMemcpy(out, c->d_ctl->prof, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (size_t i = cnt; i < static_cast<size_t>(n); ++i) out[i] = 0;
+    return RT_OK;
+#else
+    c->err = "rt_debug_work_counters: this build carries no step counters (use librt_mi355x_work.so)";
+    return RT_ERR_UNSUPPORTED;
+#endif
 }
 
 // ---- host scene wrappers ------------------------------------------------------------------------------------

@@ -156,6 +156,7 @@ struct DFrame {              // which pixels this launch covers
     uint32_t item_cap, ray_cap;   // per-shard capacity of the shade-item and bounce-ray lists
 };
 
+#define RT_WORK_SHADOW 640
 #define RT_QUEUE_SHARDS 8
 #define RT_STAT_SHARDS 64
 // Compaction lists (shade items, bounce rays) are split into RT_LIST_SHARDS sub-lists, each with its own counter on its
@@ -188,7 +189,7 @@ struct Control {
     // whose arithmetic needs < 20 us.)
     unsigned long long stat[RT_STAT_SHARDS][16];
     // -DRT_PROFILE builds only: executed work (wave steps) and useful lane work per leaf mode / box tests
-    unsigned long long prof[640];
+    unsigned long long prof[768];            // [0, 96): step counters of the trace kernels; [RT_WORK_SHADOW, +96): of the shadow kernels; between: histograms
     // LAST member, NOT covered by the per-frame memset (kFrameClearBytes): set by a kernel whose list reservation did not fit (never
     // expected: the capacities are derived from the tile counts).  Sticky, so that asynchronous frames (rt_render_device without stats,
     // graph replays) cannot lose it; every synchronising entry point turns it into an error and clears it.

@@ -344,8 +344,9 @@ __device__ __forceinline__ float lane_f(float v, int src_lane) {
 #ifdef RT_PROFILE
 // profiling build: wave-level step counters, flushed with one atomic per leaf/inner visit (slow, diagnostic only)
 __device__ unsigned long long *g_prof = nullptr;
+__device__ uint32_t g_prof_base = 0u;       // step counters of the launch in flight go to prof[g_prof_base + idx]: 0 = trace kernels, RT_WORK_SHADOW = shadow kernels
 #ifdef RT_PROFILE_STEPS
-#define RT_PROF_ADD(lane, idx, val) do { const unsigned long long pv_ = static_cast<unsigned long long>(val); if ((lane) == 0 && g_prof) atomicAdd(&g_prof[(idx)], pv_); } while (0)
+#define RT_PROF_ADD(lane, idx, val) do { const unsigned long long pv_ = static_cast<unsigned long long>(val); if ((lane) == 0 && g_prof) atomicAdd(&g_prof[g_prof_base + (idx)], pv_); } while (0)
 #else
 #define RT_PROF_ADD(lane, idx, val) do { } while (0)   // RT_PROFILE alone: only the per-unit cycle histogram (undistorted)
 #endif
@@ -1440,6 +1441,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
     for (uint32_t work = 0; q.next(work);) {
         uint32_t unit = work;
         WalkCtl wc = walk_plain();
+        RT_PROF_ADD(lane, 13, 1);
         if (CONT) {
             const ContTask task = Q.tasks_in[work];
             unit = uniform_u32(task.unit);
@@ -1647,6 +1649,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
 #endif
         uint32_t unit = work;
         WalkCtl wc = walk_plain();
+        RT_PROF_ADD(lane, 13, 1);
 #ifdef RT_PROFILE
         wc.pc = &pclk;
 #endif
@@ -1845,6 +1848,7 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         pclk.to(6);
         const unsigned long long unit_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
+        RT_PROF_ADD(lane, 13, 1);
         uint32_t sh, lu, n_sh;
         shard_find(imap, unit, sh, lu, n_sh);
         const uint32_t g = P == 1u ? lu : udiv(lu, P, inv_P), pass = lu - g * P;                       // (hit, light) pair of the list shard, pass of it
@@ -2320,10 +2324,10 @@ void launch_primary_probe(int grid, hipStream_t st, const DCam *cam, int W, int 
 }
 
 #ifdef RT_PROFILE
-__global__ void k_set_prof(Control *ctl) { g_prof = ctl->prof; }
-void launch_set_prof(hipStream_t st, Control *ctl) { hipLaunchKernelGGL(k_set_prof, dim3(1), dim3(1), 0, st, ctl); }
+__global__ void k_set_prof(Control *ctl, uint32_t base) { g_prof = ctl->prof; g_prof_base = base; }
+void launch_set_prof(hipStream_t st, Control *ctl, uint32_t base) { hipLaunchKernelGGL(k_set_prof, dim3(1), dim3(1), 0, st, ctl, base); }
 #else
-void launch_set_prof(hipStream_t, Control *) {}
+void launch_set_prof(hipStream_t, Control *, uint32_t) {}
 #endif
 
 // ------------------------------------------------------------------------------------------------------

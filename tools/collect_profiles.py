@@ -1,7 +1,9 @@
 # Assembles profiles/traffic.json and profiles/valu.json from the outputs of tools/traffic.sh and tools/valu.sh
 # (gpurun_out/traffic_<scene>/traffic_<scene>.json, gpurun_out/valu_<scene>/valu_<scene>.json).
-import json, os, sys
+import hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the PMC constants are only quoted by bench.py while they belong to the kernels source that is being timed
+SHA = hashlib.sha256(open(os.path.join(ROOT, "raytracer-in-cpp_amd", "csrc", "rt_kernels.hip"), "rb").read()).hexdigest()
 cfg = {"cube": "1920x1080 depth 4 64 samples", "dodge": "1920x1080 depth 4 64 samples", "wavy": "3840x2160 depth 8 256 samples"}
 traffic_path, valu_path = os.path.join(ROOT, "profiles", "traffic.json"), os.path.join(ROOT, "profiles", "valu.json")
 traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
@@ -9,6 +11,10 @@ valu = json.load(open(valu_path)) if os.path.exists(valu_path) else {}
 
 
 def shadow_kernel(d, cont):
+    if not cont:
+        for k in d:
+            if "k_shadow_shaft" in k:
+                return k
     for k in d:
         if "k_shadow<false" in k and k.rstrip(">").endswith("true" if cont else "false"):
             return k
@@ -26,11 +32,11 @@ for sc in cfg:
             "how": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --scene {sc} --steps 2 --warmup 1` "
                    "(tools/traffic.sh); level-0 launch; FETCH_SIZE doubled per the gfx950 rule of MI355X_MICROARCH.md §HBM (calibrated there "
                    "for 16-B/lane streams; our mix of 64-B scalar and 16-B lane loads is uncalibrated)",
-            "config": cfg[sc]}
+            "config": cfg[sc], "kernels_sha256": SHA}
     p = os.path.join(ROOT, "gpurun_out", f"valu_{sc}", f"valu_{sc}.json")
     if os.path.exists(p):
         d = json.load(open(p))
-        ent = {"config": cfg[sc], "how": f"rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE over `bench.py --scene {sc} --steps 2 --warmup 1` "
+        ent = {"config": cfg[sc], "kernels_sha256": SHA, "how": f"rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE over `bench.py --scene {sc} --steps 2 --warmup 1` "
                                           "(tools/valu.sh); heaviest (level-0) launch of each kernel; gpu_cycles = GRBM_GUI_ACTIVE / 8 XCDs",
                "kernels": {}}
         for k, v in d.items():

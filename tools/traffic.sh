@@ -6,8 +6,8 @@ sc=${1:-cube}; tag=${2:-traffic}; shift 2
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/$tag
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/$tag/f -o f --output-format csv -- python3 $R/bench.py --scene $sc --steps 2 --warmup 1 --no-cpu-baseline "$@" > $R/gpurun_out/$tag/f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/$tag/w -o w --output-format csv -- python3 $R/bench.py --scene $sc --steps 2 --warmup 1 --no-cpu-baseline "$@" > $R/gpurun_out/$tag/w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/$tag/f -o f --output-format csv -- python3 $R/bench.py --scene $sc --steps 2 --warmup 1 --no-cpu-baseline --no-tree-scenes --no-work-counters "$@" > $R/gpurun_out/$tag/f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/$tag/w -o w --output-format csv -- python3 $R/bench.py --scene $sc --steps 2 --warmup 1 --no-cpu-baseline --no-tree-scenes --no-work-counters "$@" > $R/gpurun_out/$tag/w.log 2>&1
 python3 - <<PY
 import csv, collections, glob, json
 out = {}
