@@ -80,7 +80,7 @@ typedef struct rt_camera {
     float viewport[4];        /* (0,0,W,H)                                                                      */
 } rt_camera;
 
-enum { RT_LIGHT_POINT = 0, RT_LIGHT_AREA = 1 };
+enum { RT_LIGHT_POINT = 0, RT_LIGHT_AREA = 1, RT_LIGHT_SPHERE = 2 };
 /* replaces: Flyscene::lights, lightrep colour, the stdin switches areaLight/pointLight (flyscene.cpp:31-34,68,72)
  * and the literals of createSpherePoint/createAreaLight (flyscene.cpp:956-972, arealight.hpp:15-25)             */
 typedef struct rt_lights {
@@ -90,6 +90,11 @@ typedef struct rt_lights {
     int32_t mode;                           /* RT_LIGHT_POINT (1 sample) | RT_LIGHT_AREA (usteps*vsteps)        */
     int32_t usteps, vsteps;                 /* 5,5 in the reference; 8,8 / 16,16 for the 64 / 256 sample configs */
     float   len_x, len_y;                   /* 0.3, 0.15                                                        */
+    /* RT_LIGHT_SPHERE: the third branch of createSpherePoint (flyscene.cpp:974-995, neither stdin switch set): sample s of a light at p
+       is offsets[s] + p, offsets[s] = Vector3f(x, y, z) / 5 of that branch.  The reference draws them from an unseeded
+       std::random_device for every shaded hit; here the caller fixes them per frame (rt_sphere_offsets gives the seeded restatement).  */
+    int32_t      n_offsets;                 /* 1..RT_MAX_SAMPLES (25 in the reference)                          */
+    const float *offsets;                   /* host, n_offsets * 3; copied by the call                           */
 } rt_lights;
 
 /* replaces: the literals inside traceRay / lightStrikes and raytraceScene's image size + thread partitioning    */
@@ -236,6 +241,11 @@ void rt_default_camera(rt_camera *cam, int32_t width, int32_t height);
 void rt_yaw_camera(rt_camera *cam, int32_t width, int32_t height, float yaw);
 /* replaces: Camera::screenToWorld (camera.hpp:155-173); host evaluation, used to check the device's              */
 void rt_screen_to_world(const rt_camera *cam, float i, float j, float out[3]);
+/* replaces: the sphere-point loop of createSpherePoint (flyscene.cpp:976-993) with std::random_device replaced by the seed: point i
+ * uses std::mt19937 gen(seed + i); std::uniform_real_distribution<> dis(0, 1) (libstdc++: generate_canonical<double, 53>), then
+ * theta = 2.0f * M_PI * r, phi = acos(2.0 * r - 1.0), (x, y, z) = radius * (sin(phi) cos(theta), sin(phi) sin(theta), cos(phi)) in float,
+ * out[i] = Vector3f(x, y, z) / 5.  radius = lightrep.getBoundingSphereRadius() (1.0: the unit sphere shape).  Host only.              */
+void rt_sphere_offsets(uint32_t seed, float radius, int32_t n, float *out);
 /* replaces: lights.push_back((-1,1,1)), lightrep colour, areaLight/pointLight stdin (flyscene.cpp:31-34,68,72)    */
 void rt_default_lights(rt_lights *l, int32_t area);
 

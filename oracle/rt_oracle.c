@@ -801,6 +801,11 @@ int orc_light_strikes(const oscene *s, const float hit[3], const float *pts, int
 /* ------------------------------------------------------------------ */
 int orc_light_samples(const olights *l, const float p[3], float *out) {
     if (l->mode == OLIGHT_POINT) { out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; return 1; }
+    if (l->mode == OLIGHT_SPHERE) {       /* pointOnSphere = Vector3f(x, y, z) / 5 + lightPoint  (flyscene.cpp:990) */
+        for (int i = 0; i < l->n_offsets; i++)
+            for (int k = 0; k < 3; k++) out[i * 3 + k] = l->offsets[i * 3 + k] + p[k];
+        return l->n_offsets;
+    }
     /* uvec = corner + lengthX*(1,0,0); vvec = corner + lengthY*(0,1,0) */
     float uvec[3] = {p[0] + l->len_x * 1.0f, p[1] + l->len_x * 0.0f, p[2] + l->len_x * 0.0f};
     float vvec[3] = {p[0] + l->len_y * 0.0f, p[1] + l->len_y * 1.0f, p[2] + l->len_y * 0.0f};
@@ -1054,6 +1059,39 @@ void orc_screen_to_world(const ocamera *c, float i, float j, float out[3]) {
     const float *m = c->inv_view;
     for (int r = 0; r < 3; r++)
         out[r] = ((m[r * 4] * n0 + m[r * 4 + 1] * n1) + m[r * 4 + 2] * n2) + m[r * 4 + 3] * 1.0f;
+}
+
+/* std::mt19937 (the first two outputs after seeding) and libstdc++'s generate_canonical<double, 53>: what
+   `std::mt19937 gen(seed); std::uniform_real_distribution<> dis(0, 1); dis(gen)` returns */
+static double mt19937_canonical(uint32_t seed) {
+    uint32_t x[400];
+    x[0] = seed;
+    for (int i = 1; i < 400; i++) x[i] = 1812433253u * (x[i - 1] ^ (x[i - 1] >> 30)) + (uint32_t)i;
+    uint32_t u[2];
+    for (int k = 0; k < 2; k++) {
+        uint32_t y = (x[k] & 0x80000000u) | (x[k + 1] & 0x7fffffffu);
+        uint32_t v = x[k + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        v ^= v >> 11; v ^= (v << 7) & 0x9d2c5680u; v ^= (v << 15) & 0xefc60000u; v ^= v >> 18;
+        u[k] = v;
+    }
+    double sum = 0.0, tmp = 1.0;
+    for (int k = 0; k < 2; k++) { sum += (double)u[k] * tmp; tmp *= 4294967296.0; }
+    double ret = sum / tmp;
+    if (ret >= 1.0) ret = nextafter(1.0, 0.0);
+    return ret;
+}
+
+void orc_sphere_offsets(uint32_t seed, float radius, int n, float *out) {
+    /* flyscene.cpp:976-993 with std::random_device replaced by seed + i */
+    for (int i = 0; i < n; i++) {
+        float randomno = (float)mt19937_canonical(seed + (uint32_t)i);
+        float theta = (float)((double)2.0f * M_PI * (double)randomno);
+        float phi = (float)acos(2.0 * (double)randomno - 1.0);
+        float x = (radius * sinf(phi)) * cosf(theta);
+        float y = (radius * sinf(phi)) * sinf(theta);
+        float z = radius * cosf(phi);
+        out[i * 3] = x / 5.0f; out[i * 3 + 1] = y / 5.0f; out[i * 3 + 2] = z / 5.0f;
+    }
 }
 
 void orc_default_lights(olights *l, int area) {

@@ -76,7 +76,7 @@ typedef struct {
     float viewport[4];
 } ocamera;
 
-enum { OLIGHT_POINT = 0, OLIGHT_AREA = 1 };
+enum { OLIGHT_POINT = 0, OLIGHT_AREA = 1, OLIGHT_SPHERE = 2 };
 
 typedef struct {
     int   nlights;
@@ -85,6 +85,8 @@ typedef struct {
     int   mode;               /* OLIGHT_POINT: stdin "1 1"; OLIGHT_AREA: stdin "1 0" */
     int   usteps, vsteps;     /* 5,5 in the reference (flyscene.cpp:971) */
     float len_x, len_y;       /* 0.3, 0.15 */
+    int   n_offsets;          /* OLIGHT_SPHERE: createSpherePoint's third branch (flyscene.cpp:974-995) with the per-frame offsets */
+    const float *offsets;     /* n_offsets*3: Vector3f(x,y,z)/5 of that branch; sample s of a light at p = offsets[s] + p */
 } olights;
 
 typedef struct {
@@ -112,7 +114,8 @@ void    orc_set_model_matrix(oscene *s, const float m[12]);
 void orc_default_camera(ocamera *c, int w, int h);           /* flyscene.cpp:46-47, flycamera.hpp:76-86 */
 void orc_yaw_camera(ocamera *c, int w, int h, float yaw);    /* flycamera.hpp:166-191 (extension: animation) */
 void orc_screen_to_world(const ocamera *c, float i, float j, float out[3]); /* camera.hpp:155-173 */
-void orc_default_lights(olights *l, int area);               /* flyscene.cpp:68,72,971 */
+void orc_default_lights(olights *l, int area);
+void orc_sphere_offsets(uint32_t seed, float radius, int n, float *out);  /* flyscene.cpp:976-993, std::random_device -> mt19937(seed + i) */               /* flyscene.cpp:68,72,971 */
 
 /* ---- per-function entry points (unit parity) ---- */
 int   orc_box_intersect(const float bmin[3], const float bmax[3], const float o[3], const float dest[3]); /* boundingBox.cpp:48-83 */

@@ -5,4 +5,5 @@ Only what the path needs lives here: csrc/ (HIP kernels + C ABI + GL-free host s
 """
 from . import capi, hipmem, shard  # noqa: F401
 from .capi import load_library  # noqa: F401
-from .flyscene import Context, Flyscene, FrameGraph, HostScene, default_camera, make_lights, make_params  # noqa: F401
+from .flyscene import (Context, Flyscene, FrameGraph, HostScene, default_camera, make_lights, make_params, set_sphere,  # noqa: F401
+                       sphere_offsets)

@@ -11,7 +11,7 @@ RT_OK = 0
 RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_IO, RT_ERR_UNSUPPORTED, RT_ERR_NO_SCENE = -1, -2, -3, -4, -5, -6
 RT_MAX_LIGHTS = 25
 RT_COMM_ID_BYTES = 128
-RT_LIGHT_POINT, RT_LIGHT_AREA = 0, 1
+RT_LIGHT_POINT, RT_LIGHT_AREA, RT_LIGHT_SPHERE = 0, 1, 2
 RT_NODE_LEAF = 0x80000000
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -46,7 +46,7 @@ class rt_camera(C.Structure):
 class rt_lights(C.Structure):
     _fields_ = [("n_lights", C.c_int32), ("pos", (C.c_float * 3) * RT_MAX_LIGHTS), ("color", C.c_float * 3),
                 ("mode", C.c_int32), ("usteps", C.c_int32), ("vsteps", C.c_int32),
-                ("len_x", C.c_float), ("len_y", C.c_float)]
+                ("len_x", C.c_float), ("len_y", C.c_float), ("n_offsets", C.c_int32), ("offsets", C.POINTER(C.c_float))]
 
 
 class rt_params(C.Structure):
@@ -112,6 +112,7 @@ _SIGNATURES = [
     ("rt_yaw_camera", None, [_P(rt_camera), C.c_int32, C.c_int32, C.c_float]),
     ("rt_screen_to_world", None, [_P(rt_camera), C.c_float, C.c_float, _P(C.c_float)]),
     ("rt_default_lights", None, [_P(rt_lights), C.c_int32]),
+    ("rt_sphere_offsets", None, [C.c_uint32, C.c_float, C.c_int32, C.c_void_p]),
     ("rt_write_ppm", C.c_int, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]),
     ("rt_write_ppm_u8", C.c_int, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]),
     ("rt_write_pfm", C.c_int, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]),

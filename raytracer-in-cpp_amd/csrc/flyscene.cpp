@@ -27,9 +27,10 @@ void Flyscene::initialize(int width, int height, bool area_light, bool point_lig
     areaLight = area_light;
     pointLight = point_light;
     if (!pointLight && !areaLight) {
-        std::cerr << "rt_mi355x: the spherical light mode draws from an unseeded std::random_device in the reference "
-                     "(flyscene.cpp:974-995) and is out of scope; using the area light" << std::endl;
-        areaLight = true;
+        // the spherical mode (flyscene.cpp:974-995): 25 points per light, drawn ONCE per initialize() from the seeded restatement of
+        // the reference's loop (it re-draws them from an unseeded std::random_device at every shaded hit: not reproducible)
+        sphere_offsets_.assign(25 * 3, 0.f);
+        rt_sphere_offsets(sphere_seed_, 1.0f, 25, sphere_offsets_.data());
     }
     view_w_ = width; view_h_ = height;
     rt_default_camera(&camera_, width, height);
@@ -62,6 +63,11 @@ void Flyscene::initialize(int width, int height, bool area_light, bool point_lig
 
 void Flyscene::fill_lights(rt_lights *l, const std::vector<Vec3f> &pts) const {
     rt_default_lights(l, (areaLight && !pointLight) ? 1 : 0);
+    if (!pointLight && !areaLight) {        // createSpherePoint's third branch
+        l->mode = RT_LIGHT_SPHERE;
+        l->n_offsets = static_cast<int32_t>(sphere_offsets_.size() / 3);
+        l->offsets = sphere_offsets_.data();
+    }
     l->n_lights = static_cast<int32_t>(pts.size());
     for (size_t i = 0; i < pts.size() && i < RT_MAX_LIGHTS; ++i) std::memcpy(l->pos[i], pts[i].data(), sizeof(float) * 3);
     l->usteps = usteps_; l->vsteps = vsteps_;
@@ -129,6 +135,10 @@ bool Flyscene::lightStrikes(Vec3f &hitPoint, std::vector<Vec3f> &lights, bool vi
 std::vector<Vec3f> Flyscene::createSpherePoint(Vec3f p) {
     std::vector<Vec3f> out;
     if (pointLight) { out.push_back(p); return out; }
+    if (!areaLight) {
+        for (size_t i = 0; i + 2 < sphere_offsets_.size(); i += 3) out.push_back({sphere_offsets_[i] + p[0], sphere_offsets_[i + 1] + p[1], sphere_offsets_[i + 2] + p[2]});
+        return out;
+    }
     // createAreaLight(lightPoint, 0.3, 0.15, usteps, vsteps).getPointLights()  (flyscene.cpp:956-971, arealight.hpp:15-25)
     const float lx = static_cast<float>(0.3), ly = static_cast<float>(0.15);
     const float ux = p[0] + lx * 1.0f, uz = p[2] + lx * 0.0f, vy = p[1] + ly * 1.0f;

@@ -68,6 +68,8 @@ private:
     rt_stats stats_{};
     rt_status last_status_ = RT_OK;
     std::vector<float> image_;
+    std::vector<float> sphere_offsets_;          // spherical light mode: Vector3f(x, y, z) / 5 per sample (rt_sphere_offsets)
+    uint32_t sphere_seed_ = 65u;                 // "CG Raytracing Group 65" (README.MD:1)
 };
 
 }  // namespace rtamd

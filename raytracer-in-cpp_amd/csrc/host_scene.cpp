@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <random>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -565,6 +566,22 @@ void screen_to_world(const rt_camera *cam, float i, float j, float out[3]) {
     n1 = n1 * scale;
     const float *m = cam->inv_view;
     for (int r = 0; r < 3; ++r) out[r] = ((m[r * 4] * n0 + m[r * 4 + 1] * n1) + m[r * 4 + 2] * n2) + m[r * 4 + 3] * 1.0f;
+}
+
+void sphere_offsets(uint32_t seed, float radius, int n, float *out) {
+    // the sphere-point loop of Flyscene::createSpherePoint (flyscene.cpp:976-993) with std::random_device replaced by seed + i; the same
+    // standard-library generator and distribution as the reference, so the offsets are what its code yields for that generator state
+    for (int i = 0; i < n; ++i) {
+        std::mt19937 gen(seed + static_cast<uint32_t>(i));
+        std::uniform_real_distribution<> dis(0, 1);
+        float randomno = dis(gen);
+        float theta = 2.0f * M_PI * randomno;
+        float phi = std::acos(2.0 * randomno - 1.0);
+        float x = radius * std::sin(phi) * std::cos(theta);
+        float y = radius * std::sin(phi) * std::sin(theta);
+        float z = radius * std::cos(phi);
+        out[i * 3] = x / 5; out[i * 3 + 1] = y / 5; out[i * 3 + 2] = z / 5;       // Vector3f / int: the int becomes a float, true division
+    }
 }
 
 void default_lights(rt_lights *l, int area) {

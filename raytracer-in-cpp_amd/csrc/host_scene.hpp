@@ -116,6 +116,7 @@ void default_camera(rt_camera *cam, int w, int h);
 void yaw_camera(rt_camera *cam, int w, int h, float yaw);
 void screen_to_world(const rt_camera *cam, float i, float j, float out[3]);
 void default_lights(rt_lights *l, int area);
+void sphere_offsets(uint32_t seed, float radius, int n, float *out);
 int write_ppm(const char *path, const float *rgb, int w, int h);
 int write_ppm_u8(const char *path, const uint8_t *rgb, int w, int h);
 

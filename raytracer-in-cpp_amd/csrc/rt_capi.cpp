@@ -87,6 +87,8 @@ struct rt_ctx {
     uint64_t frame_generation = 0;    // bumped whenever the frame buffers are reallocated (invalidates captured graphs)
     uint64_t scene_generation = 0;    // bumped by every rt_upload_scene: a captured graph holds the scene's device pointers by value
     hipEvent_t cam_events[512] = {};  // one per camera-ring slot: recorded after the slot's H2D copy, waited for before the slot is reused
+    float *d_offsets = nullptr;  // RT_LIGHT_SPHERE sample offsets of the last call
+    size_t cap_offsets = 0;
     float *d_rgb = nullptr;      // staging for rt_render (host output)
     int32_t *d_hit = nullptr;
     float *d_t = nullptr;
@@ -186,6 +188,7 @@ extern "C" void rt_destroy(rt_ctx *c) {
     free_scene(c);
     free_frame(c);
     if (c->d_rgb) (void)hipFree(c->d_rgb);
+    if (c->d_offsets) (void)hipFree(c->d_offsets);
     if (c->d_hit) (void)hipFree(c->d_hit);
     if (c->d_t) (void)hipFree(c->d_t);
     if (c->d_ctl) (void)hipFree(c->d_ctl);
@@ -494,8 +497,12 @@ extern "C" int32_t rt_local_rows(const rt_params *p) {
 
 static rt_status check_lights(rt_ctx *c, const rt_lights *l, DLights *out) {
     if (!l || l->n_lights < 1 || l->n_lights > RT_MAX_LIGHTS) { c->err = "lights: n_lights must be in 1..25 (the reference overflows bool[25] beyond)"; return RT_ERR_INVALID; }
-    if (l->mode != RT_LIGHT_POINT && l->mode != RT_LIGHT_AREA) { c->err = "lights: mode must be point or area (the unseeded spherical mode is out of scope)"; return RT_ERR_INVALID; }
+    if (l->mode != RT_LIGHT_POINT && l->mode != RT_LIGHT_AREA && l->mode != RT_LIGHT_SPHERE) { c->err = "lights: mode must be point, area or sphere"; return RT_ERR_INVALID; }
     int ns = 1;
+    if (l->mode == RT_LIGHT_SPHERE) {
+        if (l->n_offsets < 1 || l->n_offsets > RT_MAX_SAMPLES || !l->offsets) { c->err = "lights: sphere mode needs 1..1024 offsets"; return RT_ERR_INVALID; }
+        ns = l->n_offsets;
+    }
     if (l->mode == RT_LIGHT_AREA) {
         if (l->usteps < 1 || l->vsteps < 1 || static_cast<long>(l->usteps) * l->vsteps > RT_MAX_SAMPLES) { c->err = "lights: usteps*vsteps must be in 1..1024"; return RT_ERR_INVALID; }
         ns = l->usteps * l->vsteps;
@@ -507,6 +514,27 @@ static rt_status check_lights(rt_ctx *c, const rt_lights *l, DLights *out) {
     out->usteps = l->mode == RT_LIGHT_AREA ? l->usteps : 1;
     out->vsteps = l->mode == RT_LIGHT_AREA ? l->vsteps : 1;
     out->n_samples = ns; out->len_x = l->len_x; out->len_y = l->len_y;
+    out->offsets = nullptr;
+    if (l->mode == RT_LIGHT_SPHERE) {
+        // the offsets travel to a context-owned device buffer (synchronous copy: sphere mode is not a latency path); their box bounds the samples
+        const size_t bytes = static_cast<size_t>(ns) * 3 * sizeof(float);
+        if (bytes > c->cap_offsets) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->d_offsets) (void)hipFree(c->d_offsets);
+            c->d_offsets = nullptr; c->cap_offsets = 0;
+            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_offsets), bytes));
+            c->cap_offsets = bytes;
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));          // a frame in flight may still read the previous offsets
+        HIPCHK(c, hipMemcpy(c->d_offsets, l->offsets, bytes, hipMemcpyHostToDevice));
+        out->offsets = c->d_offsets;
+        for (int k = 0; k < 3; ++k) { out->obox[k] = l->offsets[k]; out->obox[3 + k] = l->offsets[k]; }
+        for (int i = 1; i < ns; ++i)
+            for (int k = 0; k < 3; ++k) {
+                out->obox[k] = std::fmin(out->obox[k], l->offsets[i * 3 + k]);
+                out->obox[3 + k] = std::fmax(out->obox[3 + k], l->offsets[i * 3 + k]);
+            }
+    }
     return RT_OK;
 }
 
@@ -1135,6 +1163,7 @@ extern "C" void rt_default_camera(rt_camera *cam, int32_t w, int32_t h) { if (ca
 extern "C" void rt_yaw_camera(rt_camera *cam, int32_t w, int32_t h, float yaw) { if (cam && w > 0 && h > 0) yaw_camera(cam, w, h, yaw); }
 extern "C" void rt_screen_to_world(const rt_camera *cam, float i, float j, float out[3]) { if (cam && out) screen_to_world(cam, i, j, out); }
 extern "C" void rt_default_lights(rt_lights *l, int32_t area) { if (l) default_lights(l, area); }
+extern "C" void rt_sphere_offsets(uint32_t seed, float radius, int32_t n, float *out) { if (out && n > 0) sphere_offsets(seed, radius, n, out); }
 
 extern "C" rt_status rt_write_ppm(const char *path, const float *rgb, int32_t w, int32_t h) {
     if (!path || !rgb || w <= 0 || h <= 0) return RT_ERR_INVALID;

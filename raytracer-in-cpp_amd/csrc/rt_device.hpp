@@ -143,6 +143,8 @@ struct DLights {
     float color[3];
     int32_t n_lights, mode, usteps, vsteps, n_samples;
     float len_x, len_y;
+    const float *offsets;    // RT_LIGHT_SPHERE: n_samples * 3 sample offsets (device); sample s of a light at p = offsets[s] + p
+    float obox[6];           // ... and their bounding box (min, max): p + obox bounds the samples (float addition is monotone)
 };
 
 struct DFrame {              // which pixels this launch covers

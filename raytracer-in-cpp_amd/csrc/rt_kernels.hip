@@ -1167,7 +1167,7 @@ __device__ __forceinline__ uint32_t shard_reserve(uint32_t *counters, uint32_t *
 // 4 x 16 strip of a 16 x 16 light): the 64 segments of a unit form a tighter bundle (-6 % on cfg4's k_shadow).  The visibility
 // word of pass p keeps bit l for lane l, so k_shade looks sample (i, j) up in word (i/8)*(vsteps/8) + j/8, bit (i%8)*8 + j%8.
 __device__ __forceinline__ bool sample_blocks(const DLights &L) {
-    return L.n_samples > 64 && (L.usteps & 7) == 0 && (L.vsteps & 7) == 0;
+    return L.mode == RT_LIGHT_AREA && L.n_samples > 64 && (L.usteps & 7) == 0 && (L.vsteps & 7) == 0;
 }
 
 // The sample grid of one light: sample (i, j) = ((i + 0.5) * cx, (j + 0.5) * cy, z).  cx and cy each hold a float division, so a
@@ -1195,6 +1195,16 @@ __device__ __forceinline__ void grid_sample(const LightGrid &g, const float fi, 
 __device__ __forceinline__ void light_sample_ij(const DLights &L, const float px, const float py, const float pz, const float fi, const float fj,
                                                 float &sx, float &sy, float &sz) {
     grid_sample(light_grid(L, px, py, pz), fi, fj, sx, sy, sz);
+}
+// RT_LIGHT_SPHERE (createSpherePoint's third branch, flyscene.cpp:974-995): sample s of a light at p = offsets[s] + p, its samples lie in
+// p + obox (float addition is monotone, so the box of the offsets bounds the samples exactly)
+__device__ __forceinline__ void sphere_sample(const DLights &L, const uint32_t s, const float px, const float py, const float pz, float &sx, float &sy, float &sz) {
+    const uint32_t k = s < static_cast<uint32_t>(L.n_samples) ? s : 0u;
+    sx = L.offsets[k * 3u] + px; sy = L.offsets[k * 3u + 1u] + py; sz = L.offsets[k * 3u + 2u] + pz;
+}
+__device__ __forceinline__ void sphere_box(const DLights &L, const float px, const float py, const float pz, float &x0, float &y0, float &z0, float &x1, float &y1,
+                                           float &z1) {
+    x0 = L.obox[0] + px; y0 = L.obox[1] + py; z0 = L.obox[2] + pz; x1 = L.obox[3] + px; y1 = L.obox[4] + py; z1 = L.obox[5] + pz;
 }
 __device__ __forceinline__ void light_sample(const DLights &L, const float px, const float py, const float pz, const int s,
                                              float &sx, float &sy, float &sz) {
@@ -1618,6 +1628,10 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
         grid_sample(lg, fi_lane, fj_lane, pre_sx, pre_sy, pre_sz);
         grid_sample(lg, 0.5f, 0.5f, pre_x0, pre_y0, pre_z0);
         grid_sample(lg, fi_last, fj_last, pre_x1, pre_y1, pre_z1);
+        if (L.mode == RT_LIGHT_SPHERE) {
+            sphere_sample(L, s_in, L.pos[0][0], L.pos[0][1], L.pos[0][2], pre_sx, pre_sy, pre_sz);
+            sphere_box(L, L.pos[0][0], L.pos[0][1], L.pos[0][2], pre_x0, pre_y0, pre_z0, pre_x1, pre_y1, pre_z1);
+        }
         if (FLAT) plane_prepare(plane, fminf(pre_x0, pre_x1), fminf(pre_y0, pre_y1), fminf(pre_z0, pre_z1), fmaxf(pre_x0, pre_x1), fmaxf(pre_y0, pre_y1),
                                 fmaxf(pre_z0, pre_z1));
     }
@@ -1709,6 +1723,10 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
             // the exact extremes
             grid_sample(lg, 0.5f, 0.5f, x0, y0, z0);
             grid_sample(lg, fi_last, fj_last, x1, y1, z1);
+            if (L.mode == RT_LIGHT_SPHERE) {
+                sphere_sample(L, s, px, py, pz, sx, sy, sz);
+                sphere_box(L, px, py, pz, x0, y0, z0, x1, y1, z1);
+            }
         }
         const float ddx = hx - sx, ddy = hy - sy, ddz = hz - sz;
         const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
@@ -1879,6 +1897,11 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         grid_sample(lg, fi, fj, sx, sy, sz);
         grid_sample(lg, b_i0, b_j0, x0, y0, z0);             // the samples are monotone in each grid index: two corners give the exact box
         grid_sample(lg, b_i1, b_j1, x1, y1, z1);
+        if (L.mode == RT_LIGHT_SPHERE) {
+            const float px = it.lmode ? it.lx : L.pos[l][0], py = it.lmode ? it.ly : L.pos[l][1], pz = it.lmode ? it.lz : L.pos[l][2];
+            sphere_sample(L, s, px, py, pz, sx, sy, sz);
+            sphere_box(L, px, py, pz, x0, y0, z0, x1, y1, z1);
+        }
         const float ddx = hx - sx, ddy = hy - sy, ddz = hz - sz;
         const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
         const unsigned long long vis_index = (static_cast<unsigned long long>(g) + static_cast<unsigned long long>(sh) * item_cap * static_cast<unsigned long long>(lslots)) * P + pass;
@@ -2125,6 +2148,7 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
                     sum += visible ? 1.0f : 0.0f;
                     float sx, sy, sz;
                     grid_sample(lg, static_cast<float>(si) + 0.5f, static_cast<float>(sj) + 0.5f, sx, sy, sz);
+                    if (L.mode == RT_LIGHT_SPHERE) sphere_sample(L, s, px, py, pz, sx, sy, sz);
                     if (++sj == vst) { sj = 0; ++si; }
                     float ldx = sx - hx, ldy = sy - hy, ldz = sz - hz;
                     normalize3(ldx, ldy, ldz);

@@ -124,6 +124,24 @@ def make_lights(points=((-1.0, 1.0, 1.0),), area=True, usteps=5, vsteps=5):
     return l
 
 
+def sphere_offsets(seed, radius=1.0, n=25):
+    """rt_sphere_offsets: createSpherePoint's sphere loop (flyscene.cpp:976-993) with std::random_device replaced by mt19937(seed + i)"""
+    lib = capi.load_library()
+    out = np.zeros((int(n), 3), np.float32)
+    lib.rt_sphere_offsets(int(seed) & 0xFFFFFFFF, float(radius), int(n), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def set_sphere(lights, offsets):
+    """switch an rt_lights to RT_LIGHT_SPHERE with the given [n, 3] float32 offsets (kept alive on the struct)"""
+    off = np.ascontiguousarray(offsets, np.float32)
+    lights._offsets_keepalive = off
+    lights.mode = capi.RT_LIGHT_SPHERE
+    lights.n_offsets = off.shape[0]
+    lights.offsets = off.ctypes.data_as(C.POINTER(C.c_float))
+    return lights
+
+
 def default_camera(width, height, yaw=0.0):
     lib = capi.load_library()
     cam = capi.rt_camera()
@@ -141,6 +159,7 @@ class Flyscene:
         self.scene_path = scene_path
         self.device = device
         self.areaLight, self.pointLight = True, False
+        self.sphere_seed, self.sphere_offsets = 65, None
         self.usteps = self.vsteps = 5
         self.max_depth = -1
         self.lights = [(-1.0, 1.0, 1.0)]
@@ -154,7 +173,8 @@ class Flyscene:
     def initialize(self, width, height, areaLight=True, pointLight=False):
         self.areaLight, self.pointLight = bool(areaLight), bool(pointLight)
         if not self.areaLight and not self.pointLight:
-            raise ValueError("the spherical light mode (unseeded std::random_device, flyscene.cpp:974-995) is out of scope")
+            # spherical mode (flyscene.cpp:974-995): 25 offsets drawn once from the seeded restatement of the reference's loop
+            self.sphere_offsets = sphere_offsets(self.sphere_seed, 1.0, 25)
         self.width, self.height = int(width), int(height)
         self.camera = default_camera(width, height)
         self.scene = HostScene(self.scene_path, 1000, 15)
@@ -162,8 +182,11 @@ class Flyscene:
         self.ctx.upload(self.scene)
 
     def _lights(self, points=None):
-        return make_lights(points if points is not None else self.lights, area=(self.areaLight and not self.pointLight),
-                           usteps=self.usteps, vsteps=self.vsteps)
+        l = make_lights(points if points is not None else self.lights, area=(self.areaLight and not self.pointLight),
+                        usteps=self.usteps, vsteps=self.vsteps)
+        if not self.areaLight and not self.pointLight:
+            set_sphere(l, self.sphere_offsets)
+        return l
 
     # reference: flyscene.cpp:519-648
     def raytraceScene(self, width=0, height=0, write_ppm=True, want_hits=False, collect_stats=False):
@@ -220,6 +243,8 @@ class Flyscene:
         p = np.asarray(lightPoint, np.float32)
         if self.pointLight:
             return p.reshape(1, 3).copy()
+        if not self.areaLight:
+            return (self.sphere_offsets + p).astype(np.float32)
         f = np.float32
         ux, uz, vy = f(p[0] + f(0.3) * f(1)), f(p[2] + f(0.3) * f(0)), f(p[1] + f(0.15) * f(1))
         out = np.empty((self.usteps * self.vsteps, 3), np.float32)

@@ -20,7 +20,8 @@ class ocamera(C.Structure):
 
 class olights(C.Structure):
     _fields_ = [("nlights", C.c_int), ("pos", (C.c_float * 3) * 25), ("color", C.c_float * 3), ("mode", C.c_int),
-                ("usteps", C.c_int), ("vsteps", C.c_int), ("len_x", C.c_float), ("len_y", C.c_float)]
+                ("usteps", C.c_int), ("vsteps", C.c_int), ("len_x", C.c_float), ("len_y", C.c_float), ("n_offsets", C.c_int),
+                ("offsets", C.POINTER(C.c_float))]
 
 
 class oparams(C.Structure):
@@ -53,6 +54,7 @@ class Oracle:
         L.orc_yaw_camera.argtypes = [C.POINTER(ocamera), C.c_int, C.c_int, C.c_float]
         L.orc_screen_to_world.argtypes = [C.POINTER(ocamera), C.c_float, C.c_float, C.POINTER(C.c_float)]
         L.orc_default_lights.argtypes = [C.POINTER(olights), C.c_int]
+        L.orc_sphere_offsets.argtypes = [C.c_uint32, C.c_float, C.c_int, C.POINTER(C.c_float)]
         L.orc_box_intersect.argtypes = [C.POINTER(C.c_float)] * 4
         L.orc_box_intersect.restype = C.c_int
         L.orc_ray_triangle.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]

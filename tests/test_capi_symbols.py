@@ -28,7 +28,7 @@ def test_struct_sizes_match_header(rt):
     c = rt.capi
     assert C.sizeof(c.rt_node) == 32 and C.sizeof(c.rt_material) == 36
     assert C.sizeof(c.rt_camera) == 4 * (3 + 12 + 1 + 1 + 4)
-    assert C.sizeof(c.rt_lights) == 4 * (1 + 75 + 3 + 3 + 2)
+    assert C.sizeof(c.rt_lights) == 4 * (1 + 75 + 3 + 3 + 2) + 4 + 4 + 8        # + n_offsets, padding, offsets pointer
     assert C.sizeof(c.rt_params) == 36
 
 

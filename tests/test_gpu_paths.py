@@ -166,3 +166,40 @@ def test_set_model_rebuild_arrays_equal_oracle(rt, oracle):
     assert np.array_equal(hs2.arrays()["node_box"].view(np.uint32), box0.view(np.uint32))
     assert np.array_equal(hs2.arrays()["tri_verts"].view(np.uint32), tri.view(np.uint32))
     osc.close(); hs.close(); hs2.close()
+
+
+# ---------------------------------------------------------------------------------------------------- spherical light
+def test_sphere_offsets_host_equals_oracle(rt, oracle):
+    """rt_sphere_offsets (libstdc++ mt19937 + uniform_real_distribution, as the reference's loop uses them) against the oracle's plain-C
+    restatement of both: bit for bit, several seeds and counts."""
+    for seed, n, radius in ((65, 25, 1.0), (0, 64, 1.0), (123456789, 25, 0.15), (4294967290, 100, 2.5)):
+        a = rt.sphere_offsets(seed, radius, n)
+        b = np.zeros((n, 3), np.float32)
+        oracle.lib.orc_sphere_offsets(seed, radius, n, b.ctypes.data_as(C.POINTER(C.c_float)))
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (seed, n)
+        r = np.sqrt((a.astype(np.float64) ** 2).sum(1)) * 5
+        assert np.allclose(r, radius, rtol=1e-5)           # points of the sphere of that radius, divided by 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,n", [("cube.obj", 25), ("dodgeColorTest.obj", 25), ("dodgeColorTest.obj", 64)])
+def test_spherical_light_mode_matches_oracle(rt, oracle, scene, n):
+    """createSpherePoint's third branch (flyscene.cpp:974-995) with seeded offsets: 25 samples (two (hit, light) pairs per wave) and 64
+    (the shaft walk), mirror bounces included (the child's light list is {hitPoint}: its samples are offsets + hitPoint)."""
+    path = os.path.join(SCENES, scene)
+    hs = rt.HostScene(path, 1000, 15)
+    ctx = rt.Context(0)
+    ctx.upload(hs)
+    osc = oracle.load_scene(path)
+    off = rt.sphere_offsets(65, 1.0, n)
+    w, h = 208, 144
+    L = rt.set_sphere(rt.make_lights(area=False), off)
+    oL = oracle.lights(area=False)
+    oL.mode = 2
+    oL.n_offsets = n
+    oL.offsets = off.ctypes.data_as(C.POINTER(C.c_float))
+    rgb, hits = render_gpu(rt, ctx, rt.default_camera(w, h), L, w, h, 3)
+    ref, rhits, _ = osc.render(oracle.camera(w, h), oL, w, h, max_depth=3, threads=8, want_hits=True)
+    assert_exact(oracle, rgb, hits, ref, rhits)
+    assert len(np.unique(ref.reshape(-1, 3), axis=0)) > 50          # soft shadows: many distinct colours
+    osc.close(); ctx.close(); hs.close()
