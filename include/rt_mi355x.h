@@ -198,6 +198,25 @@ int32_t rt_local_rows(const rt_params *p);
 rt_status rt_trace_rays(rt_ctx *ctx, const rt_lights *lights, int32_t max_depth, int32_t n,
                         const float *origin, const float *dir, float *out_rgb, int32_t *out_face, float *out_t);
 
+/* replaces: the computational part of Flyscene::createDebugRay / recursiveDebugRay (flyscene.cpp:241-430, 433-470; the cylinders, spheres
+ * and console prints are GL / GUI and out of scope).  Level 0 starts at the screen point of the pixel with dir = (screen - centre).normalized();
+ * every level records the closest hit of (pos, dir), the hit point p0 = pos + t * dir, the face normal, lightStrikes(p0, lights), the colour
+ * traceRay returns for that ray, and continues along reflectedDir = dir - 2 * dir.dot(n) * n from p0 (flyscene.cpp:349), until a miss or
+ * max_levels records.  (The reference re-uses the PRIMARY ray's root test and candidate set at every level and keeps negative t,
+ * flyscene.cpp:247-259 -- a visualiser quirk that is not reproduced: each level here traces its own ray.)                              */
+typedef struct rt_debug_hit {
+    int32_t level;
+    int32_t status;                 /* 0: the ray misses the root box (the reference draws it red), 1: box but no triangle (blue), 2: hit (green) */
+    int32_t face;                   /* closest face id, -1 without a hit                                                          */
+    float   t;
+    float   pos[3], dir[3];         /* the ray of this level                                                                      */
+    float   hit_point[3], normal[3], reflected[3], color[3];
+    uint8_t light_visible[RT_MAX_LIGHTS];
+    uint8_t pad[3];
+} rt_debug_hit;
+rt_status rt_debug_ray(rt_ctx *ctx, const rt_camera *cam, const rt_lights *lights, float pixel_x, float pixel_y, int32_t max_levels,
+                       rt_debug_hit *out, int32_t *n_out);
+
 /* replaces: Flyscene::lightStrikes (flyscene.cpp:912-954): n segments light[i] -> hit[i]; vis[i] = 1 iff visible   */
 rt_status rt_light_strikes(rt_ctx *ctx, int32_t n, const float *hit, const float *light, uint8_t *vis);
 

@@ -55,6 +55,12 @@ class rt_params(C.Structure):
                 ("nranks", C.c_int32), ("collect_stats", C.c_int32)]
 
 
+class rt_debug_hit(C.Structure):
+    _fields_ = [("level", C.c_int32), ("status", C.c_int32), ("face", C.c_int32), ("t", C.c_float), ("pos", C.c_float * 3), ("dir", C.c_float * 3),
+                ("hit_point", C.c_float * 3), ("normal", C.c_float * 3), ("reflected", C.c_float * 3), ("color", C.c_float * 3),
+                ("light_visible", C.c_uint8 * RT_MAX_LIGHTS), ("pad", C.c_uint8 * 3)]
+
+
 class rt_stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_bounce", C.c_uint64), ("rays_centre", C.c_uint64),
                 ("rays_sample", C.c_uint64), ("pixels", C.c_uint64), ("pixels_culled", C.c_uint64),
@@ -97,6 +103,7 @@ _SIGNATURES = [
     ("rt_local_rows", C.c_int32, [_P(rt_params)]),
     ("rt_trace_rays", C.c_int, [C.c_void_p, _P(rt_lights), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),
+    ("rt_debug_ray", C.c_int, [C.c_void_p, _P(rt_camera), _P(rt_lights), C.c_float, C.c_float, C.c_int32, _P(rt_debug_hit), _P(C.c_int32)]),
     ("rt_light_strikes", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rt_box_intersect", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rt_tree_probe", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

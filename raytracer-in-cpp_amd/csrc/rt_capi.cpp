@@ -1035,6 +1035,55 @@ extern "C" rt_status rt_light_strikes(rt_ctx *c, int32_t n, const float *hit, co
     return s;
 }
 
+// ---- debug ray (createDebugRay / recursiveDebugRay without the GL shapes): a host composition of the entry points above ------------
+extern "C" rt_status rt_debug_ray(rt_ctx *c, const rt_camera *cam, const rt_lights *lights, float px, float py, int32_t max_levels, rt_debug_hit *out,
+                                  int32_t *n_out) {
+    if (!c) return RT_ERR_INVALID;
+    if (!cam || !lights || !out || !n_out || max_levels < 1) { c->err = "rt_debug_ray: bad arguments"; return RT_ERR_INVALID; }
+    if (!c->has_scene) { c->err = "rt_debug_ray before rt_upload_scene"; return RT_ERR_NO_SCENE; }
+    *n_out = 0;
+    float scr[3];
+    screen_to_world(cam, px, py, scr);                                              // flyscene.cpp:439
+    V3 pos{scr[0], scr[1], scr[2]};
+    V3 dir = unit_fixed(pos - V3{cam->center[0], cam->center[1], cam->center[2]});   // flyscene.cpp:441
+    for (int32_t n = 0; n < max_levels; ++n) {
+        rt_debug_hit &r = out[n];
+        std::memset(&r, 0, sizeof r);
+        r.level = n; r.face = -1;
+        r.pos[0] = pos.x; r.pos[1] = pos.y; r.pos[2] = pos.z; r.dir[0] = dir.x; r.dir[1] = dir.y; r.dir[2] = dir.z;
+        // root box: boxIntersect(origin, origin + direction), as traceRay tests it (flyscene.cpp:655)
+        const float dest[3] = {pos.x + dir.x, pos.y + dir.y, pos.z + dir.z};
+        DNode root;
+        HIPCHK(c, hipMemcpy(&root, c->d_nodes, sizeof root, hipMemcpyDeviceToHost));
+        uint8_t in_box = 0;
+        const float boxes[6] = {root.bmin[0], root.bmin[1], root.bmin[2], root.bmax[0], root.bmax[1], root.bmax[2]};
+        rt_status s = rt_box_intersect(c, 1, boxes, r.pos, dest, &in_box);
+        if (s != RT_OK) return s;
+        int32_t face = -1; float t = -1.0f;
+        s = rt_trace_rays(c, lights, 0, 1, r.pos, r.dir, r.color, &face, &t);
+        if (s != RT_OK) return s;
+        *n_out = n + 1;
+        r.status = !in_box ? 0 : (face < 0 ? 1 : 2);
+        if (face < 0) break;
+        r.face = face; r.t = t;
+        const V3 p0 = pos + V3{t * dir.x, t * dir.y, t * dir.z};                   // flyscene.cpp:270
+        r.hit_point[0] = p0.x; r.hit_point[1] = p0.y; r.hit_point[2] = p0.z;
+        float nrm[3];
+        HIPCHK(c, hipMemcpy(nrm, static_cast<const float *>(c->d_face_normal) + static_cast<size_t>(face) * 3, sizeof nrm, hipMemcpyDeviceToHost));
+        std::memcpy(r.normal, nrm, sizeof nrm);
+        const V3 nv{nrm[0], nrm[1], nrm[2]};
+        float hit[RT_MAX_LIGHTS * 3];
+        const int nl = lights->n_lights < 1 ? 0 : (lights->n_lights > RT_MAX_LIGHTS ? RT_MAX_LIGHTS : lights->n_lights);
+        for (int i = 0; i < nl; ++i) { hit[i * 3] = p0.x; hit[i * 3 + 1] = p0.y; hit[i * 3 + 2] = p0.z; }
+        if (nl && (s = rt_light_strikes(c, nl, hit, &lights->pos[0][0], r.light_visible)) != RT_OK) return s;      // flyscene.cpp:273
+        const float two = 2 * dot(dir, nv);
+        const V3 refl = dir - V3{two * nv.x, two * nv.y, two * nv.z};              // flyscene.cpp:349
+        r.reflected[0] = refl.x; r.reflected[1] = refl.y; r.reflected[2] = refl.z;
+        pos = p0; dir = refl;
+    }
+    return RT_OK;
+}
+
 // ---- unit-parity probes ---------------------------------------------------------------------------------------------
 namespace {
 struct DevBuf {          // scoped device allocation for the probe entry points

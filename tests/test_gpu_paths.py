@@ -203,3 +203,57 @@ def test_spherical_light_mode_matches_oracle(rt, oracle, scene, n):
     assert_exact(oracle, rgb, hits, ref, rhits)
     assert len(np.unique(ref.reshape(-1, 3), axis=0)) > 50          # soft shadows: many distinct colours
     osc.close(); ctx.close(); hs.close()
+
+
+@pytest.mark.gpu
+def test_debug_ray_chain_matches_oracle_composition(rt, oracle):
+    """rt_debug_ray = createDebugRay / recursiveDebugRay's computational steps (flyscene.cpp:241-470) as a chain of the C-ABI entry points;
+    checked against the same chain spelt with the oracle's closest_hit / light_strikes / trace_ray."""
+    path = os.path.join(SCENES, "cube.obj")
+    hs = rt.HostScene(path, 1000, 15)
+    ctx = rt.Context(0)
+    ctx.upload(hs)
+    osc = oracle.load_scene(path)
+    w = h = 256
+    cam, ocam = rt.default_camera(w, h), oracle.camera(w, h)
+    L, oL = rt.make_lights(area=True), oracle.lights(area=True)
+    fn = osc.arrays()["face_normal"]
+    seen = set()
+    for (px, py) in ((128, 128), (64, 128), (150, 100), (0, 0), (131, 123)):
+        rec = (rt.capi.rt_debug_hit * 6)()
+        n = C.c_int32()
+        st = ctx.lib.rt_debug_ray(ctx.handle, C.byref(cam), C.byref(L), float(px), float(py), 6, rec, C.byref(n))
+        rt.capi.check(ctx.lib, ctx.handle, st, "rt_debug_ray")
+        scr = oracle.screen_to_world(ocam, px, py)
+        pos = scr.copy()
+        d = (scr - np.array(ocam.center, np.float32)).astype(np.float32)
+        q = np.float32(d[0] * d[0] + np.float32(d[1] * d[1] + d[2] * d[2]))
+        d = (d / np.float32(np.sqrt(q))).astype(np.float32)
+        for k in range(n.value):
+            r = rec[k]
+            assert np.array_equal(np.array(r.pos, np.float32).view(np.uint32), pos.view(np.uint32)), (px, py, k)
+            assert np.array_equal(np.array(r.dir, np.float32).view(np.uint32), d.view(np.uint32)), (px, py, k)
+            face, t = osc.closest_hit(pos, d)
+            root = osc.node(0)["box"]
+            in_box = oracle.lib.orc_box_intersect(root[0:3].copy().ctypes.data_as(C.POINTER(C.c_float)), root[3:6].copy().ctypes.data_as(C.POINTER(C.c_float)),
+                                                  pos.ctypes.data_as(C.POINTER(C.c_float)), (pos + d).astype(np.float32).ctypes.data_as(C.POINTER(C.c_float)))
+            assert r.status == (0 if not in_box else (2 if face >= 0 else 1))
+            seen.add(r.status)
+            assert r.face == face
+            col = osc.trace_ray(oL, pos, d, max_depth=0)
+            assert np.array_equal(np.array(r.color, np.float32).view(np.uint32), col.view(np.uint32))
+            if face < 0:
+                assert k == n.value - 1
+                break
+            assert np.float32(r.t).view(np.uint32) == np.float32(t).view(np.uint32)
+            p0 = (pos + np.float32(t) * d).astype(np.float32)
+            assert np.array_equal(np.array(r.hit_point, np.float32).view(np.uint32), p0.view(np.uint32))
+            _, vis = osc.light_strikes(p0, np.array([[-1.0, 1.0, 1.0]], np.float32))
+            assert bool(r.light_visible[0]) == bool(vis[0])
+            nv = fn[face]
+            two = np.float32(2) * np.float32(d[0] * nv[0] + np.float32(d[1] * nv[1] + d[2] * nv[2]))
+            refl = (d - two * nv).astype(np.float32)
+            assert np.array_equal(np.array(r.reflected, np.float32).view(np.uint32), refl.view(np.uint32))
+            pos, d = p0, refl
+    assert 2 in seen and len(seen) >= 2
+    osc.close(); ctx.close(); hs.close()
