@@ -147,9 +147,98 @@ static void affine_identity(float m[12]) {
 
 static void compute_world(oscene *s);
 
+/* ---- PLY (plyimporter.hpp:186-262 via rply): the reference's PLY path fills GL buffers only and never builds the faces the ray tracer
+   reads, so no reference semantics exist; defined as "the mesh loadObjFile would build from the same data": x,y,z (w = 1), the
+   file's nx,ny,nz as the vn list, the first three indices of every face list (face_cb, plyimporter.hpp:104-118), no materials. ---- */
+typedef struct { char name[64]; int size; char kind; int list; int csize; char ckind; } plyprop;
+typedef struct { char name[64]; long count; plyprop props[32]; int nprops; } plyelem;
+static int ply_type(const char *t, int *size, char *kind) {
+    static const struct { const char *n; int s; char k; } T[] = {
+        {"char", 1, 'i'}, {"int8", 1, 'i'}, {"uchar", 1, 'u'}, {"uint8", 1, 'u'}, {"short", 2, 'i'}, {"int16", 2, 'i'}, {"ushort", 2, 'u'}, {"uint16", 2, 'u'},
+        {"int", 4, 'i'}, {"int32", 4, 'i'}, {"uint", 4, 'u'}, {"uint32", 4, 'u'}, {"float", 4, 'f'}, {"float32", 4, 'f'}, {"double", 8, 'f'}, {"float64", 8, 'f'}};
+    for (size_t i = 0; i < sizeof T / sizeof T[0]; i++) if (strcmp(t, T[i].n) == 0) { *size = T[i].s; *kind = T[i].k; return 1; }
+    return 0;
+}
+static int ply_scalar(FILE *f, int ascii, int size, char kind, double *out) {
+    if (ascii) return fscanf(f, "%lf", out) == 1;
+    unsigned char b[8];
+    if (fread(b, 1, (size_t)size, f) != (size_t)size) return 0;
+    if (kind == 'f') { if (size == 4) { float v; memcpy(&v, b, 4); *out = v; } else { double v; memcpy(&v, b, 8); *out = v; } return 1; }
+    uint64_t u = 0;
+    for (int i = size - 1; i >= 0; i--) u = (u << 8) | b[i];
+    if (kind == 'i') {
+        int64_t v = size == 1 ? (int8_t)u : size == 2 ? (int16_t)u : (int32_t)u;
+        *out = (double)v;
+    } else *out = (double)u;
+    return 1;
+}
+/* fills vert (x,y,z,1), norm (nx,ny,nz) and one index group; returns 0 on a malformed file */
+static int load_ply_arrays(const char *path, float **vert, int *nv, float **norm, int *nn, ogroup *grp) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "oracle: cannot open %s\n", path); return 0; }
+    char line[1024];
+    if (!fgets(line, sizeof line, f) || strncmp(line, "ply", 3) != 0) { fclose(f); return 0; }
+    int ascii = 0, have_format = 0, ne = 0;
+    plyelem *el = calloc(16, sizeof(plyelem));
+    while (fgets(line, sizeof line, f)) {
+        char key[64] = "", a[64] = "", b[64] = "", c[64] = "", d[64] = "";
+        int n = sscanf(line, "%63s %63s %63s %63s %63s", key, a, b, c, d);
+        if (n < 1) continue;
+        if (strcmp(key, "end_header") == 0) break;
+        if (strcmp(key, "format") == 0) { ascii = strcmp(a, "ascii") == 0; if (!ascii && strcmp(a, "binary_little_endian") != 0) { fclose(f); free(el); return 0; } have_format = 1; }
+        else if (strcmp(key, "element") == 0 && ne < 16) { snprintf(el[ne].name, 64, "%s", a); el[ne].count = atol(b); el[ne].nprops = 0; ne++; }
+        else if (strcmp(key, "property") == 0 && ne > 0 && el[ne - 1].nprops < 32) {
+            plyprop *p = &el[ne - 1].props[el[ne - 1].nprops++];
+            memset(p, 0, sizeof *p);
+            if (strcmp(a, "list") == 0) { p->list = 1; if (!ply_type(b, &p->csize, &p->ckind) || !ply_type(c, &p->size, &p->kind)) { fclose(f); free(el); return 0; } snprintf(p->name, 64, "%s", d); }
+            else { if (!ply_type(a, &p->size, &p->kind)) { fclose(f); free(el); return 0; } snprintf(p->name, 64, "%s", b); }
+        }
+    }
+    if (!have_format) { fclose(f); free(el); return 0; }
+    int cv = 0, cn = 0, ok = 1;
+    *nv = 0; *nn = 0; *vert = NULL; *norm = NULL;
+    for (int e = 0; e < ne && ok; e++) {
+        int is_v = strcmp(el[e].name, "vertex") == 0, is_f = strcmp(el[e].name, "face") == 0;
+        for (long i = 0; i < el[e].count && ok; i++) {
+            float v[3] = {0, 0, 0}, nr[3] = {0, 0, 0}; int have_nz = 0;
+            for (int k = 0; k < el[e].nprops && ok; k++) {
+                const plyprop *p = &el[e].props[k];
+                double val = 0;
+                if (p->list) {
+                    double cnt = 0;
+                    if (!ply_scalar(f, ascii, p->csize, p->ckind, &cnt)) { ok = 0; break; }
+                    for (long j = 0; j < (long)cnt; j++) {
+                        if (!ply_scalar(f, ascii, p->size, p->kind, &val)) { ok = 0; break; }
+                        if (is_f && strcmp(p->name, "vertex_indices") == 0 && j < 3) grp_push(grp, (unsigned)val);
+                    }
+                } else {
+                    if (!ply_scalar(f, ascii, p->size, p->kind, &val)) { ok = 0; break; }
+                    if (is_v) {
+                        if (strcmp(p->name, "x") == 0) v[0] = (float)val; else if (strcmp(p->name, "y") == 0) v[1] = (float)val;
+                        else if (strcmp(p->name, "z") == 0) v[2] = (float)val; else if (strcmp(p->name, "nx") == 0) nr[0] = (float)val;
+                        else if (strcmp(p->name, "ny") == 0) nr[1] = (float)val; else if (strcmp(p->name, "nz") == 0) { nr[2] = (float)val; have_nz = 1; }
+                    }
+                }
+            }
+            if (is_v && ok) {
+                if (*nv == cv) { cv = cv ? cv * 2 : 1024; *vert = realloc(*vert, sizeof(float) * 4 * (size_t)cv); }
+                (*vert)[*nv * 4] = v[0]; (*vert)[*nv * 4 + 1] = v[1]; (*vert)[*nv * 4 + 2] = v[2]; (*vert)[*nv * 4 + 3] = 1.0f; (*nv)++;
+                if (have_nz) {
+                    if (*nn == cn) { cn = cn ? cn * 2 : 1024; *norm = realloc(*norm, sizeof(float) * 3 * (size_t)cn); }
+                    (*norm)[*nn * 3] = nr[0]; (*norm)[*nn * 3 + 1] = nr[1]; (*norm)[*nn * 3 + 2] = nr[2]; (*nn)++;
+                }
+            }
+        }
+    }
+    fclose(f); free(el);
+    return ok;
+}
+
 oscene *orc_load_obj(const char *obj_path) {
-    FILE *f = fopen(obj_path, "r");
-    if (!f) { fprintf(stderr, "oracle: cannot open %s\n", obj_path); return NULL; }
+    const char *ext = strrchr(obj_path, '.');
+    const int is_ply = ext && (strcmp(ext, ".ply") == 0 || strcmp(ext, ".PLY") == 0);
+    FILE *f = is_ply ? NULL : fopen(obj_path, "r");
+    if (!f && !is_ply) { fprintf(stderr, "oracle: cannot open %s\n", obj_path); return NULL; }
     oscene *s = calloc(1, sizeof(oscene));
     char dir[1024]; { /* getPathName, objimporter.hpp:44-48 */
         const char *sl = strrchr(obj_path, '/'); const char *bs = strrchr(obj_path, '\\');
@@ -162,7 +251,8 @@ oscene *orc_load_obj(const char *obj_path) {
     ogroup *grp = calloc(1, sizeof(ogroup)); int ng = 1; grp[0].mat = -1;
     int current_mat = -1;
     char *line = NULL; size_t cap = 0;
-    while (read_line(f, &line, &cap)) {
+    if (is_ply && !load_ply_arrays(obj_path, &vert, &nv, &norm, &nn, &grp[0])) { fprintf(stderr, "oracle: bad PLY %s\n", obj_path); free(grp); free(s); return NULL; }
+    while (!is_ply && read_line(f, &line, &cap)) {
         size_t len = strlen(line);
         if (len >= 6 && strncmp(line, "mtllib", 6) == 0) {
             if (len < 7) continue;
@@ -200,7 +290,7 @@ oscene *orc_load_obj(const char *obj_path) {
             }
         }
     }
-    free(line); fclose(f);
+    free(line); if (f) fclose(f);
 
     /* computeNormals (objimporter.hpp:50-74): APPENDS nverts zero normals to the file's vn list and accumulates
        unit face normals at normals[vertex_id] -- i.e. into the file's vn slots when the file has any. */

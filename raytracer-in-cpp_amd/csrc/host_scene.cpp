@@ -4,6 +4,7 @@
 #include "host_scene.hpp"
 
 #include <algorithm>
+#include <cctype>
 #include <cfloat>
 #include <cmath>
 #include <random>
@@ -86,7 +87,121 @@ bool HostScene::load_mtl(const std::string &path) {
 // ---------------------------------------------------------------------------------------------------------
 // OBJ (objimporter.hpp:83-284)
 // ---------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------
+// PLY (plyimporter.hpp:186-262 through rply).  Tucano's PLY path only fills GL buffers -- it never calls storeVertexData / createFaces,
+// so the reference cannot ray-trace a PLY mesh at all (mesh.getNumberOfFaces() == 0).  Defined here as: the SAME mesh state
+// loadObjFile would build from the same data -- positions (x, y, z, 1), the file's per-vertex normals as the `vn` list (then the
+// importer's normal-accumulation quirk), the first three indices of every face list (plyimporter.hpp:104-118), no materials
+// (-> the default Mtl).  ascii and binary_little_endian; parity unpinned (no reference render can exist).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct PlyProp { std::string name; int size = 0; char kind = 'f'; bool list = false; int count_size = 0; char count_kind = 'u'; };
+struct PlyElem { std::string name; size_t count = 0; std::vector<PlyProp> props; };
+
+bool ply_type(const std::string &t, int *size, char *kind) {
+    static const struct { const char *n; int s; char k; } T[] = {
+        {"char", 1, 'i'}, {"int8", 1, 'i'}, {"uchar", 1, 'u'}, {"uint8", 1, 'u'}, {"short", 2, 'i'}, {"int16", 2, 'i'}, {"ushort", 2, 'u'}, {"uint16", 2, 'u'},
+        {"int", 4, 'i'}, {"int32", 4, 'i'}, {"uint", 4, 'u'}, {"uint32", 4, 'u'}, {"float", 4, 'f'}, {"float32", 4, 'f'}, {"double", 8, 'f'}, {"float64", 8, 'f'}};
+    for (const auto &e : T) if (t == e.n) { *size = e.s; *kind = e.k; return true; }
+    return false;
+}
+// one scalar as the double rply's ply_get_argument_value returns
+bool ply_scalar(std::istream &in, bool ascii, int size, char kind, double *out) {
+    if (ascii) { return static_cast<bool>(in >> *out); }
+    unsigned char b[8];
+    if (!in.read(reinterpret_cast<char *>(b), size)) return false;
+    if (kind == 'f') {
+        if (size == 4) { float f; std::memcpy(&f, b, 4); *out = f; } else { double d; std::memcpy(&d, b, 8); *out = d; }
+    } else {
+        unsigned long long u = 0;
+        for (int i = size - 1; i >= 0; --i) u = (u << 8) | b[i];
+        if (kind == 'i') {
+            const unsigned long long sign = 1ull << (size * 8 - 1);
+            *out = (u & sign) ? -static_cast<double>((~u + 1ull) & ((sign << 1) - 1ull)) : static_cast<double>(u);
+        } else *out = static_cast<double>(u);
+    }
+    return true;
+}
+}  // namespace
+
+bool HostScene::load_ply(const std::string &path, std::string *err) {
+    std::ifstream in(path.c_str(), std::ios::in | std::ios::binary);
+    if (!in) { if (err) *err = "cannot open " + path; return false; }
+    std::string line;
+    if (!std::getline(in, line) || line.substr(0, 3) != "ply") { if (err) *err = "not a PLY file: " + path; return false; }
+    bool ascii = false, have_format = false;
+    std::vector<PlyElem> elems;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::istringstream ls(line);
+        std::string key;
+        ls >> key;
+        if (key == "end_header") break;
+        if (key == "format") {
+            std::string f; ls >> f;
+            if (f == "ascii") ascii = true;
+            else if (f != "binary_little_endian") { if (err) *err = "unsupported PLY format " + f; return false; }
+            have_format = true;
+        } else if (key == "element") {
+            PlyElem e; ls >> e.name >> e.count; elems.push_back(e);
+        } else if (key == "property" && !elems.empty()) {
+            PlyProp p; std::string t; ls >> t;
+            if (t == "list") {
+                std::string ct, it; ls >> ct >> it >> p.name;
+                p.list = true;
+                if (!ply_type(ct, &p.count_size, &p.count_kind) || !ply_type(it, &p.size, &p.kind)) { if (err) *err = "bad PLY list type"; return false; }
+            } else {
+                ls >> p.name;
+                if (!ply_type(t, &p.size, &p.kind)) { if (err) *err = "bad PLY type " + t; return false; }
+            }
+            elems.back().props.push_back(p);
+        }
+    }
+    if (!have_format) { if (err) *err = "PLY header without a format line"; return false; }
+    verts.clear(); normals.clear(); tris.clear(); mats.clear();
+    std::vector<MeshGroup> groups(1);
+    for (const PlyElem &e : elems) {
+        for (size_t i = 0; i < e.count; ++i) {
+            std::array<float, 4> v{0.f, 0.f, 0.f, 1.f};
+            V3 n; bool have_nz = false;
+            for (const PlyProp &p : e.props) {
+                if (p.list) {
+                    double cnt = 0;
+                    if (!ply_scalar(in, ascii, p.count_size, p.count_kind, &cnt)) { if (err) *err = "truncated PLY"; return false; }
+                    for (long k = 0; k < static_cast<long>(cnt); ++k) {
+                        double val = 0;
+                        if (!ply_scalar(in, ascii, p.size, p.kind, &val)) { if (err) *err = "truncated PLY"; return false; }
+                        if (e.name == "face" && p.name == "vertex_indices" && k < 3) groups[0].ids.push_back(static_cast<uint32_t>(val));   // face_cb: value_index 0..2
+                    }
+                } else {
+                    double val = 0;
+                    if (!ply_scalar(in, ascii, p.size, p.kind, &val)) { if (err) *err = "truncated PLY"; return false; }
+                    if (e.name == "vertex") {
+                        if (p.name == "x") v[0] = static_cast<float>(val);
+                        else if (p.name == "y") v[1] = static_cast<float>(val);
+                        else if (p.name == "z") v[2] = static_cast<float>(val);
+                        else if (p.name == "nx") n.x = static_cast<float>(val);
+                        else if (p.name == "ny") n.y = static_cast<float>(val);
+                        else if (p.name == "nz") { n.z = static_cast<float>(val); have_nz = true; }
+                    }
+                }
+            }
+            if (e.name == "vertex") {
+                verts.push_back(v);
+                if (have_nz) normals.push_back(n);            // normal_cb pushes when nz arrives
+            }
+        }
+    }
+    return finish_mesh(groups, path, err);
+}
+
 bool HostScene::load_obj(const std::string &path, std::string *err) {
+    const size_t dot = path.find_last_of('.');
+    if (dot != std::string::npos) {
+        std::string ext = path.substr(dot);
+        for (char &ch : ext) ch = static_cast<char>(std::tolower(static_cast<unsigned char>(ch)));
+        if (ext == ".ply") return load_ply(path, err);
+    }
     std::ifstream in(path.c_str(), std::ios::in);
     if (!in) {
         if (err) *err = "cannot open " + path;
@@ -96,7 +211,7 @@ bool HostScene::load_obj(const std::string &path, std::string *err) {
     const std::string dir = cut == std::string::npos ? std::string() : path.substr(0, cut + 1);
 
     verts.clear(); normals.clear(); tris.clear(); mats.clear();
-    struct Group { std::vector<uint32_t> ids; int mat = -1; };
+    typedef MeshGroup Group;
     std::vector<Group> groups(1);
     int current = -1;
 
@@ -134,6 +249,12 @@ bool HostScene::load_obj(const std::string &path, std::string *err) {
             }
         }
     }
+    return finish_mesh(groups, path, err);
+}
+
+// everything after the file has been parsed: the same for OBJ and PLY
+bool HostScene::finish_mesh(const std::vector<MeshGroup> &groups, const std::string &path, std::string *err) {
+    typedef MeshGroup Group;
     if (verts.empty()) {
         if (err) *err = "no vertices in " + path;
         return false;

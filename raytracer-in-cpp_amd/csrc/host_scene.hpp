@@ -70,7 +70,10 @@ struct OctNode {
 class HostScene {
 public:
     // import + normalise (flyscene.cpp:50-56)
-    bool load_obj(const std::string &path, std::string *err);
+    struct MeshGroup { std::vector<uint32_t> ids; int mat = -1; };       // one index group (a usemtl block; PLY: the whole file)
+    bool load_obj(const std::string &path, std::string *err);            // .obj, or .ply by extension
+    bool load_ply(const std::string &path, std::string *err);
+    bool finish_mesh(const std::vector<MeshGroup> &groups, const std::string &path, std::string *err);
     // BoxTree(mesh, capacity) with MAX_DEPTH (flyscene.cpp:86-93, boxTree.cpp:3,11-31)
     void build_octree(int capacity, int max_depth);
     // BoxTree -> rt_scene arrays
