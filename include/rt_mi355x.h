@@ -243,6 +243,10 @@ rt_status rt_host_scene_view(const rt_host_scene *hs, rt_scene *out);
 /* replaces: Flyscene::modifyTriangle (flyscene.cpp:998-1015): sets the model matrix; rebuild != 0 also rebuilds
  * the octree (the reference leaves it stale)                                                                     */
 rt_status rt_host_scene_set_model(rt_host_scene *hs, const float model[12], int32_t rebuild_tree);
+/* replaces: BoxTree(mesh, capacity) / split / clasifyFace (src/boxTree.cpp:11-31,88-147,203-336) evaluated ON THE DEVICE of `ctx`
+ * (level-synchronous classify + stable compaction, rt_build.hip): rebuilds the octree of the host scene's current world vertices and
+ * re-flattens it.  The result equals the host build (rt_host_scene_load / _set_model(rebuild)) array for array.                   */
+rt_status rt_host_scene_build_gpu(rt_host_scene *hs, rt_ctx *ctx, int32_t leaf_capacity, int32_t max_depth);
 /* tree summary: nodes, non-empty leaves, face refs, largest leaf, depth, "lost" faces                             */
 rt_status rt_host_scene_info(const rt_host_scene *hs, int32_t out[8], float root_box[6]);
 

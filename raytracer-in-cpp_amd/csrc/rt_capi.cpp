@@ -35,6 +35,7 @@ void launch_segments(int grid, hipStream_t st, const DScene &S, int n, const flo
 void launch_box_probe(hipStream_t st, int n, const float *box, const float *org, const float *dst, uint8_t *out);
 void launch_tree_probe(int grid, hipStream_t st, const DScene &S, int n, const float *org, const float *dst, uint32_t *out_box, uint32_t *out_ref, uint32_t *out_sig);
 void launch_primary_probe(int grid, hipStream_t st, const DCam *cam, int W, int H, float *out);
+bool gpu_build_octree(HostScene &hs, int cap, int depth, hipStream_t st, std::string *err);
 void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow, int *shade);
 void launch_set_prof(hipStream_t st, Control *ctl, uint32_t base);
 }  // namespace rtamd
@@ -1200,6 +1201,16 @@ extern "C" rt_status rt_host_scene_set_model(rt_host_scene *hs, const float mode
     if (!hs || !model) return RT_ERR_INVALID;
     hs->hs.set_model(model, rebuild_tree != 0);
     return hs->hs.overflow ? RT_ERR_UNSUPPORTED : RT_OK;
+}
+
+extern "C" rt_status rt_host_scene_build_gpu(rt_host_scene *hs, rt_ctx *c, int32_t leaf_capacity, int32_t max_depth) {
+    if (!hs || !c || leaf_capacity < 1 || max_depth < 0 || max_depth > 15) return RT_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::string err;
+    if (!gpu_build_octree(hs->hs, leaf_capacity, max_depth, c->stream, &err)) { c->err = "rt_host_scene_build_gpu: " + err; return RT_ERR_HIP; }
+    if (hs->hs.overflow) return RT_ERR_UNSUPPORTED;
+    hs->hs.flatten();
+    return RT_OK;
 }
 
 extern "C" rt_status rt_host_scene_info(const rt_host_scene *hs, int32_t out[8], float root_box[6]) {

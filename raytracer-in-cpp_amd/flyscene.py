@@ -35,6 +35,11 @@ class HostScene:
         capi.check(self.lib, None, self.lib.rt_host_scene_set_model(self.handle, m, 1 if rebuild_tree else 0), "set_model")
         self._refresh()
 
+    def build_gpu(self, ctx, leaf_capacity=1000, max_depth=15):
+        """rt_host_scene_build_gpu: the reference's octree construction on the device of `ctx` (same result as the host build)"""
+        capi.check(self.lib, ctx.handle, self.lib.rt_host_scene_build_gpu(self.handle, ctx.handle, int(leaf_capacity), int(max_depth)), "rt_host_scene_build_gpu")
+        self._refresh()
+
     def info(self):
         out = (C.c_int32 * 8)()
         box = (C.c_float * 6)()
