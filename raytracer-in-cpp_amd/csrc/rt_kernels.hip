@@ -1082,7 +1082,11 @@ __device__ __forceinline__ void shaft_walk(const DNode *__restrict__ nodes, cons
         while (surv != 0ull) {
             const int j = static_cast<int>(__builtin_ctzll(surv));
             surv &= surv - 1ull;
-            const DNode nd = node_from_lane(ch, 8 * j);
+            // the survivor's record as wave-uniform values: an LDS broadcast read where the group sits in the LDS copy of the top of the
+            // tree (4 ds_read_b128), else 16 v_readlane from the lane that loaded it (cfg4: -2.5 % on k_shadow_shaft).  Measured and
+            // rejected here: skipping the per-ray content test on inner nodes (+8 % on cfg4), prefetching the next unit's item with a
+            // scalar load (+4 %: 16 more live SGPRs -> spills), 2x / 4x / 8x larger k_stage grids (0 %).
+            const DNode nd = (base + gcnt <= sl.n_lds) ? sl.nodes[base + static_cast<uint32_t>(j)] : node_from_lane(ch, 8 * j);
             bool h = ((gm >> lane) & 1ull) != 0ull && !occluded;
             if (nd.pad[1] == 0u) {   // per-ray content test (as packet_walk): no countable point of the segment inside the subtree's content box
                 const float t0x = (nd.clo[0] - R.slab_pad - ox) * R.idx, t1x = (nd.chi[0] + R.slab_pad - ox) * R.idx;
