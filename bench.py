@@ -47,16 +47,19 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md, c
 BOX_BYTES, TRI_REF_BYTES = 24, 52   # algorithmic bytes per box test / per leaf triangle reference
 RT_WORK_SHADOW = 640            # rt_device.hpp: offset of the shadow kernels' step counters in Control::prof
 
-# VALU wave-instructions per wave-level step (read off the gfx950 listing of the shipped kernels, `make isa`)
+# VALU wave-instructions per wave-level step: static counts of each loop body in the gfx950 listing of the shipped kernels (`make isa`;
+# DESIGN.md 6).  The model lands within ~15 % of SQ_INSTS_VALU (profiles/valu.json), which is quoted beside it.
 COST = {
-    "tri_lanes_triangles": 58,   # one ray broadcast against the 64 triangles of a chunk: rayTriangleIntersection + 6 v_readlane
-    "tri_lanes_rays": 45,        # one triangle against the wave's 64 rays (scalar / LDS-staged leaves, flat scenes)
-    "node_per_ray": 72,          # a surviving child: 16 v_readlane + content test (25) + verified boxIntersect (~30)
+    "tri_lanes_triangles": 68,   # one ray broadcast against the 64 triangles of a chunk: rayTriangleIntersection + 6 v_readlane + hit bookkeeping (137 per 2-ray iteration)
+    "tri_lanes_rays": 45,        # one triangle against the wave's 64 rays (flat scenes: cube)
+    "tri_lanes_rays_shaft": 57,  # the same step in the shaft kernel (triangles that survive the per-triangle shaft test; 114 per 2-triangle iteration)
+    "node_per_ray": 90,          # a surviving child: record broadcast + content test + verified boxIntersect + masks (the IEEE-division fallback not counted)
     "box_stack_walk": 55,        # stack walk (packet_walk) child: content test + verified boxIntersect
-    "shaft_group": 75,           # lane = (child, test): two separating tests + ballots + byte reduction
-    "leaf_chunk_batch": 45,      # lane = (chunk, test) on 8 chunk bounds
-    "chunk_per_ray": 34,         # per-ray conservative chunk test (7 v_readlane + 25)
-    "unit_shaft": 180,           # k_shadow_shaft per unit: item, sample, root test, shaft planes, queue
+    "shaft_group": 90,           # lane = (child, test): group pop, two separating tests, ballots, byte reduction
+    "leaf_chunk_batch": 73,      # lane = (chunk, test) on 8 chunk bounds
+    "chunk_per_ray": 39,         # per-ray conservative chunk test (7 v_readlane + slab test)
+    "tri_shaft_test": 140,       # lane = triangle: 3 vertex boxes against 6 tangent planes + near box + the (t <= 0 or |t| >= 0.98) plane rule
+    "unit_shaft": 270,           # k_shadow_shaft per unit: queue, item, sample, root test, shaft planes (make_shaft_lanes ~95), LDS records
     "unit_flat": 250,            # flat k_shadow per unit: item, sample, root test, plane culling, queue
     "unit_stack": 200,
 }
@@ -103,21 +106,22 @@ def work_counters(pkg, hs, W, H, G, D):
     s = a[RT_WORK_SHADOW:RT_WORK_SHADOW + 96]
     t = a[0:96]
     names = {0: "tri_steps_lanes_rays", 2: "tri_steps_lanes_triangles", 4: "box_steps_stack_walk", 12: "chunk_tests_stack_walk", 13: "units",
-             88: "shaft_groups", 90: "nodes_tested_per_ray", 91: "nodes_hit", 92: "leaf_chunk_batches", 94: "chunks_tested_per_ray", 95: "chunks_with_work"}
+             88: "shaft_groups", 90: "nodes_tested_per_ray", 91: "nodes_hit", 92: "leaf_chunk_batches", 94: "chunks_tested_per_ray", 95: "chunks_with_work",
+             70: "tri_shaft_tests", 71: "tri_shaft_survivors", 72: "tri_shaft_rays", 73: "tri_shaft_empty_chunks"}
     return {"shadow": {v: s[k] for k, v in names.items()}, "trace": {v: t[k] for k, v in names.items()}}
 
 
 def valu_model(work, flat, shaft):
     """modelled VALU wave-instructions of the shadow kernels of the frame: (useful, total)"""
     w = work["shadow"]
-    useful = w["tri_steps_lanes_triangles"] * COST["tri_lanes_triangles"] + w["tri_steps_lanes_rays"] * COST["tri_lanes_rays"]
+    useful = w["tri_steps_lanes_triangles"] * COST["tri_lanes_triangles"] + w["tri_steps_lanes_rays"] * COST["tri_lanes_rays_shaft" if shaft and not flat else "tri_lanes_rays"]
     if flat:
         return useful, useful + w["units"] * COST["unit_flat"]
     if shaft:
         useful += w["nodes_tested_per_ray"] * COST["node_per_ray"]
         total = useful + w["units"] * COST["unit_shaft"] + w["shaft_groups"] * COST["shaft_group"] + w["leaf_chunk_batches"] * COST["leaf_chunk_batch"] + \
-            w["chunks_tested_per_ray"] * COST["chunk_per_ray"]
-        # leaf tasks handed to the stack-walk launch (k_shadow<.., CONT>) report their chunk tests / triangle steps through the same counters
+            w["chunks_tested_per_ray"] * COST["chunk_per_ray"] + w["tri_shaft_tests"] * COST["tri_shaft_test"]
+        # (the leaf-task launch runs the same leaf code and reports through the same counters)
         total += w["chunk_tests_stack_walk"] * 30
         return useful, total
     useful += w["box_steps_stack_walk"] * COST["box_stack_walk"]

@@ -42,7 +42,7 @@ static_assert(sizeof(TriRec) == 80, "TriRec must be 80 bytes");
 struct alignas(16) ChunkBound {
     float lo[3], hi[3];      // AABB of the chunk's triangles, inflated
     float never;             // 0: the chunk may be culled; 2: never (ill-conditioned / degenerate / non-finite triangle inside)
-    float pad;
+    float infl;              // the inflation: the point of an accepted hit lies within `infl` (per axis) of the TRIANGLE it was accepted for
 };
 static_assert(sizeof(ChunkBound) == 32, "ChunkBound must be 32 bytes");
 

@@ -452,6 +452,7 @@ __device__ __forceinline__ void leaf_visit(const DNode &nd, const uint32_t ni, c
             {
                 const ChunkBound bd = cbounds[c0 >> 6];
                 if (bd.never < 1.5f) {
+                    RT_PROF_ADD(lane, 12, 1);
                     const float t0x = (bd.lo[0] - slab_pad - ox) * idx_, t1x = (bd.hi[0] + slab_pad - ox) * idx_;
                     const float t0y = (bd.lo[1] - slab_pad - oy) * idy_, t1y = (bd.hi[1] + slab_pad - oy) * idy_;
                     const float t0z = (bd.lo[2] - slab_pad - oz) * idz_, t1z = (bd.hi[2] + slab_pad - oz) * idz_;
@@ -847,8 +848,71 @@ __device__ __forceinline__ bool ballot_byte_any(const unsigned long long b, cons
     return ((b >> ((lane & 7) * 8)) & 0xffull) != 0ull;
 }
 
+// ---- lane = triangle: one 64-triangle chunk against the unit's shaft --------------------------------------------------------------
+// A counted hit of triangle T (0.00001 < t < 0.98 and the barycentric test of rayTriangleIntersection passed IN FLOAT) has its computed
+// point within ChunkBound::infl (per axis) of T itself (rt_capi.cpp: build_chunk_bounds -- the chunk box is the union of exactly these
+// neighbourhoods), and that point lies on its segment up to rounding, i.e. inside hull(S, h).  So T cannot be hit by ANY ray of the unit
+// when the three boxes [v - m, v + m] around its vertices (m = 1.0625 * infl: B and C are re-derived as A + edge, one rounding each)
+// lie strictly outside one of the shaft's tangent planes (their convex hull contains T's neighbourhood) or outside the near box; the
+// planes carry the same margins as in the node / chunk tests.  Independently, plane_rules_out (round 1, flat scenes) proves from the
+// reference's own two dot products that t <= 0 or |t| >= 0.98 for every sample of S: this is what removes the face h lies on and its
+// coplanar neighbours, which no geometric test can separate from h.
+// The unit's planes are kept as a per-wave LDS record (written once per unit by the lanes that own them) so that the test costs no
+// register for the rest of the walk: 11 broadcast ds_read_b128.
+#define RT_SHAFT_TRI_REC 11           // float4 per wave: 6 planes (a_u, a_v, c, |a_u| + |a_v|), near box lo / hi, (h, m0), S lo, S hi
+__device__ __forceinline__ void shaft_tri_store(float4 *rec, const int lane, const ShaftLanes &SL, const float hx, const float hy, const float hz,
+                                                const float slx, const float sly, const float slz, const float shx, const float shy, const float shz) {
+    const int proj = (lane & 7) >> 1;
+    const float ax = SL.r[0] + SL.r[1], ay = SL.r[2] + SL.r[3], az = SL.r[4] + SL.r[5];        // (one addend is zero: exact)
+    const float au = proj == 1 ? ay : ax, av = proj == 2 ? ay : az;
+    if (lane < 6) rec[lane] = make_float4(au, av, SL.r[6], fabsf(au) + fabsf(av));
+    if (lane == 6) { rec[6] = make_float4(SL.r[0], SL.r[1], SL.r[2], 0.f); rec[7] = make_float4(SL.r[3], SL.r[4], SL.r[5], 0.f); }
+    if (lane == 7) {
+        const float m0 = 2e-5f * ((fabsf(slx) + fabsf(shx)) + (fabsf(sly) + fabsf(shy)) + (fabsf(slz) + fabsf(shz)) + (fabsf(hx) + fabsf(hy) + fabsf(hz)));
+        rec[8] = make_float4(hx, hy, hz, m0); rec[9] = make_float4(slx, sly, slz, 0.f); rec[10] = make_float4(shx, shy, shz, 0.f);
+    }
+}
+__device__ __forceinline__ bool tri_outside_shaft(const float4 *rec, const TriRec &tr, const float m) {
+    const float bx = tr.ax + tr.e1x, by = tr.ay + tr.e1y, bz = tr.az + tr.e1z;
+    const float cx = tr.ax + tr.e0x, cy = tr.ay + tr.e0y, cz = tr.az + tr.e0z;
+    bool out = false;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        const float4 pl = rec[p];
+        const int proj = p >> 1;
+        const float ua = proj == 1 ? tr.ay : tr.ax, ub = proj == 1 ? by : bx, uc = proj == 1 ? cy : cx;
+        const float va = proj == 2 ? tr.ay : tr.az, vb = proj == 2 ? by : bz, vc = proj == 2 ? cy : cz;
+        const float fa = __builtin_fmaf(pl.x, ua, pl.y * va), fb = __builtin_fmaf(pl.x, ub, pl.y * vb), fc = __builtin_fmaf(pl.x, uc, pl.y * vc);
+        out = out || (fminf(fminf(fa, fb), fc) + (pl.z - m * pl.w) > 0.0f);
+    }
+    const float4 lo = rec[6], hi = rec[7];
+    out = out || (fminf(fminf(tr.ax, bx), cx) - m > hi.x) || (fmaxf(fmaxf(tr.ax, bx), cx) + m < lo.x)
+              || (fminf(fminf(tr.ay, by), cy) - m > hi.y) || (fmaxf(fmaxf(tr.ay, by), cy) + m < lo.y)
+              || (fminf(fminf(tr.az, bz), cz) - m > hi.z) || (fmaxf(fmaxf(tr.az, bz), cz) + m < lo.z);
+    const float4 h = rec[8], s0 = rec[9], s1 = rec[10];
+    const SegPacket g{true, false, h.x, h.y, h.z, s0.x, s0.y, s0.z, s1.x, s1.y, s1.z, h.w};
+    return out || plane_rules_out(g, tr.nx, tr.ny, tr.nz, tr.nA);
+}
+#ifndef RT_RAYMODE_EXTRA
+#define RT_RAYMODE_EXTRA 8u          // scalar loads of the survivors' records
+#endif
+#ifndef RT_TRI_SHAFT_MIN
+#define RT_TRI_SHAFT_MIN 8            // live rays on a chunk from which the per-triangle test (~3 triangle steps) is run
+#endif
+
 #define RT_LEAF_SLOTS 16
 #define RT_COST_TRI_STEP 58u
+
+struct ShaftLds {
+    const DNode *nodes;            // LDS copy of the first n_lds nodes (the top of the breadth-first array)
+    uint32_t n_lds;
+    uint32_t *lnode;               // per-wave leaf list (RT_LEAF_SLOTS)
+    unsigned long long *lmask;
+    float4 *tri;                   // per-wave shaft record of the lane = triangle test (RT_SHAFT_TRI_REC)
+#ifdef RT_PROFILE
+    PhaseClock *pc;
+#endif
+};
 
 // One leaf of the shaft walk.  Chunk bounds are shaft-tested 8 at a time (lane = (chunk, test)); what survives goes through the per-ray
 // chunk test (lane = ray) and the triangle tests (lane = triangle); the next chunk's records are loaded while the current one is processed.
@@ -859,9 +923,11 @@ struct ShaftTasks {
     uint32_t cap, budget, target, unit;
 };
 
+template <bool TASKS>
 __device__ __forceinline__ void shaft_leaf(const uint32_t ni, const uint32_t first, const uint32_t cnt, const uint32_t chunk0, const TriRec *__restrict__ tris,
                                            const ChunkBound *__restrict__ chunks, const int lane, const RayLane &R, const ShaftLanes &SL, const ShaftTasks &TQ,
-                                           unsigned long long live, bool &occluded) {
+                                           const ShaftLds &sl, const uint32_t c_begin, const uint32_t c_end, unsigned long long live, bool &occluded) {
+    const float4 *__restrict__ srec = sl.tri;
     const float ox = R.ox, oy = R.oy, oz = R.oz, dx = R.dx, dy = R.dy, dz = R.dz;
     const TriRec *__restrict__ T = tris + first;
     bool mine = ((live >> lane) & 1ull) != 0ull;
@@ -877,7 +943,7 @@ __device__ __forceinline__ void shaft_leaf(const uint32_t ni, const uint32_t fir
         const bool ok = mine && !(tr.flags & 1u) && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f);
         occluded = occluded || (ok && t < 0.98f);
     };
-    if (cnt <= RT_SCALAR_LEAF_MAX && static_cast<uint32_t>(__popcll(live)) * RT_COST_TRI_STEP > cnt * RT_COST_RAY_MODE) {
+    if (c_begin == 0u && cnt <= RT_SCALAR_LEAF_MAX && static_cast<uint32_t>(__popcll(live)) * RT_COST_TRI_STEP > cnt * RT_COST_RAY_MODE) {
         // small leaf, many rays: every lane steps through the wave-uniform records (scalar loads)
         uint32_t k = 0;
         for (; k + 1u < cnt; k += 2u) {
@@ -889,15 +955,16 @@ __device__ __forceinline__ void shaft_leaf(const uint32_t ni, const uint32_t fir
         if (k < cnt) test_lane(tri_load_uniform(T + k));
         return;
     }
-    const uint32_t nchunk = (cnt + 63u) >> 6;
+    const uint32_t nchunk_all = (cnt + 63u) >> 6;
+    const uint32_t nchunk = c_end < nchunk_all ? c_end : nchunk_all;                  // chunks [c_begin, nchunk) are processed here
     const ChunkBound *__restrict__ cbounds = chunks + chunk0;
     const int tk = lane & 7, tc = lane >> 3;
     unsigned long long occ_new = 0ull;
-    uint32_t c_first = 0u;
+    uint32_t c_first = c_begin;
     // A big leaf with many live rays is not ground through by this wave (one unit crossing a 979-triangle leaf with 64 rays is ~60k
     // instructions: the tail of the whole launch): it becomes chunk-range tasks for the leaf-task launch, which merges its occluded
     // bits into `vis` with atomicAnd.  Estimate as leaf_visit: a third of the chunks survive the per-ray test.
-    if (TQ.budget != 0u) {
+    if (TASKS && TQ.budget != 0u) {
         const uint32_t est = nchunk * RT_COST_CHUNK_TEST + static_cast<uint32_t>(__popcll(live)) * ((nchunk + 2u) / 3u) * RT_COST_TRI_STEP;
         if (est > TQ.budget) {
             uint32_t ntask = (est + TQ.target - 1u) / TQ.target;
@@ -963,8 +1030,54 @@ __device__ __forceinline__ void shaft_leaf(const uint32_t ni, const uint32_t fir
             if (nxt_j >= 0) nxt = load_chunk(nxt_j);
             const uint32_t c0 = (cb0 + static_cast<uint32_t>(cur)) * 64u;
             const uint32_t n = cnt - c0 < 64u ? cnt - c0 : 64u;
-            const bool hast = static_cast<uint32_t>(lane) < n && !(tr.flags & 1u);
+            bool hast = static_cast<uint32_t>(lane) < n && !(tr.flags & 1u);
             unsigned long long todo = todo_cur & live;
+            const uint32_t m_rays = static_cast<uint32_t>(__popcll(todo));
+            unsigned long long tmask = ~0ull;
+            if (m_rays >= RT_TRI_SHAFT_MIN && lane_f(bd.never, 8 * cur) < 1.5f) {
+                // lane = triangle: which triangles of the chunk can be hit by ANY ray of the unit
+                RT_PH(sl, 4);
+                __builtin_amdgcn_wave_barrier();
+                hast = hast && !tri_outside_shaft(srec, tr, lane_f(bd.infl, 8 * cur) * 1.0625f);
+                tmask = __ballot(hast);
+                RT_PROF_ADD(lane, 70, 1); RT_PROF_ADD(lane, 71, __popcll(tmask)); RT_PROF_ADD(lane, 72, m_rays); RT_PROF_ADD(lane, 73, tmask == 0ull ? 1 : 0);
+            }
+            RT_PH(sl, 5);
+            if (tmask == 0ull) {
+                todo = 0ull;
+            } else if (tmask != ~0ull && static_cast<uint32_t>(__popcll(tmask)) * (RT_COST_RAY_MODE + RT_RAYMODE_EXTRA) < m_rays * RT_COST_TRI_STEP) {
+                // few triangles left, many rays: lanes = rays step through the survivors (wave-uniform records, scalar loads)
+                const bool my = ((todo >> lane) & 1ull) != 0ull;
+                bool occ_r = false;
+                const TriRec *__restrict__ Tc = T + c0;
+                auto hit_lane = [&](const TriRec &ta) -> bool {
+                    // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 (lanes = rays)
+                    const float dn = dot3(dx, dy, dz, ta.nx, ta.ny, ta.nz);
+                    const float t = (ta.nA - dot3(ox, oy, oz, ta.nx, ta.ny, ta.nz)) / dn;
+                    const float v2x = (ox + t * dx) - ta.ax, v2y = (oy + t * dy) - ta.ay, v2z = (oz + t * dz) - ta.az;
+                    const float d02 = dot3(ta.e0x, ta.e0y, ta.e0z, v2x, v2y, v2z);
+                    const float d12 = dot3(ta.e1x, ta.e1y, ta.e1z, v2x, v2y, v2z);
+                    const float u = (ta.d11 * d02 - ta.d01 * d12) * ta.inv_denom;
+                    const float v = (ta.d00 * d12 - ta.d01 * d02) * ta.inv_denom;
+                    return my && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f) && (t < 0.98f);
+                };
+                while (tmask != 0ull) {
+                    const uint32_t j0 = static_cast<uint32_t>(__builtin_ctzll(tmask));
+                    tmask &= tmask - 1ull;
+                    const bool two = tmask != 0ull;
+                    const uint32_t j1 = two ? static_cast<uint32_t>(__builtin_ctzll(tmask)) : j0;
+                    if (two) tmask &= tmask - 1ull;
+                    RT_PROF_ADD(lane, 0, two ? 2 : 1);
+                    TriRec ta, tb;
+                    tri_load_uniform_pair(Tc + j0, Tc + j1, ta, tb);
+                    const bool ha = hit_lane(ta), hb = hit_lane(tb);
+                    occ_r = occ_r || ha || hb;
+                    if (__ballot(my && !occ_r) == 0ull) break;
+                }
+                const unsigned long long ob = __ballot(occ_r);
+                occ_new |= ob; live &= ~ob;
+                todo = 0ull;
+            }
             while (todo != 0ull) {
                 const int r0 = static_cast<int>(__builtin_ctzll(todo));
                 todo &= todo - 1ull;
@@ -993,6 +1106,7 @@ __device__ __forceinline__ void shaft_leaf(const uint32_t ni, const uint32_t fir
                 if (__ballot(inq[0] && tq[0] < 0.98f) != 0ull) { occ_new |= 1ull << r0; live &= ~(1ull << r0); }
                 if (__ballot(inq[1] && tq[1] < 0.98f) != 0ull) { occ_new |= 1ull << r1; live &= ~(1ull << r1); }
             }
+            RT_PH(sl, 3);
             if (live == 0ull) break;
             cur = nxt_j; tr = nxt; todo_cur = todo_nxt;
         }
@@ -1000,15 +1114,6 @@ __device__ __forceinline__ void shaft_leaf(const uint32_t ni, const uint32_t fir
     occluded = occluded || (((occ_new >> lane) & 1ull) != 0ull);
 }
 
-struct ShaftLds {
-    const DNode *nodes;            // LDS copy of the first n_lds nodes (the top of the breadth-first array)
-    uint32_t n_lds;
-    uint32_t *lnode;               // per-wave leaf list (RT_LEAF_SLOTS)
-    unsigned long long *lmask;
-#ifdef RT_PROFILE
-    PhaseClock *pc;
-#endif
-};
 
 __device__ __forceinline__ DNode node_from_lane(const DNode &mine, const int j) {
     DNode o;
@@ -1024,6 +1129,7 @@ __device__ __forceinline__ DNode node_from_lane(const DNode &mine, const int j) 
     return o;
 }
 
+template <bool TASKS>
 __device__ __forceinline__ void shaft_walk(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris, const ChunkBound *__restrict__ chunks,
                                            const WaveStack stk, const ShaftLds sl, const int lane, const DNode &root, const bool in_root,
                                            const RayLane &R, const float brx, const float bry, const float brz, const ShaftLanes &SL, const ShaftTasks &TQ, bool &occluded) {
@@ -1053,7 +1159,7 @@ __device__ __forceinline__ void shaft_walk(const DNode *__restrict__ nodes, cons
                 uint32_t lf, lc, l0;
                 if (li < sl.n_lds) { lf = sl.nodes[li].first; lc = sl.nodes[li].count_flags; l0 = sl.nodes[li].pad[0]; }
                 else { lf = nodes[li].first; lc = nodes[li].count_flags; l0 = nodes[li].pad[0]; }
-                shaft_leaf(li, uniform_u32(lf), uniform_u32(lc) & 0x7fffffffu, uniform_u32(l0), tris, chunks, lane, R, SL, TQ, lm, occluded);
+                shaft_leaf<TASKS>(li, uniform_u32(lf), uniform_u32(lc) & 0x7fffffffu, uniform_u32(l0), tris, chunks, lane, R, SL, TQ, sl, 0u, 0xffffffffu, lm, occluded);
             }
             nleaf = 0;
             continue;
@@ -1085,7 +1191,8 @@ __device__ __forceinline__ void shaft_walk(const DNode *__restrict__ nodes, cons
             // the survivor's record as wave-uniform values: an LDS broadcast read where the group sits in the LDS copy of the top of the
             // tree (4 ds_read_b128), else 16 v_readlane from the lane that loaded it (cfg4: -2.5 % on k_shadow_shaft).  Measured and
             // rejected here: skipping the per-ray content test on inner nodes (+8 % on cfg4), prefetching the next unit's item with a
-            // scalar load (+4 %: 16 more live SGPRs -> spills), 2x / 4x / 8x larger k_stage grids (0 %).
+            // scalar load (+4 %: 16 more live SGPRs -> spills) or through one VGPR with the queue looking one unit ahead (+6 %: the
+            // other waves of the SIMD already cover that latency), 2x / 4x / 8x larger k_stage grids (0 %).
             const DNode nd = (base + gcnt <= sl.n_lds) ? sl.nodes[base + static_cast<uint32_t>(j)] : node_from_lane(ch, 8 * j);
             bool h = ((gm >> lane) & 1ull) != 0ull && !occluded;
             if (nd.pad[1] == 0u) {   // per-ray content test (as packet_walk): no countable point of the segment inside the subtree's content box
@@ -1809,24 +1916,26 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
 // K2 on TREE scenes with one (hit, light) pair -- or one 64-sample pass of it -- per wave (N >= 33 samples): the shaft walk.
 // Same units, same queue and same output words as k_shadow<false, false, false>.
 // ======================================================================================================
+template <bool CONT, bool TASKS>
 __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(RT_SHADOW_WPE, 8)))
 void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris, const ChunkBound *__restrict__ chunks,
                     const DScene S, const DLights L, const int level, const int ctr_slot, const int lslots, const uint32_t item_cap,
                     const ShadeItem *__restrict__ items, Control *__restrict__ ctl, unsigned long long *__restrict__ vis, const TaskQueues Q) {
     __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
     __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
-    __shared__ uint4 s_top[RT_LDS_NODES * 4];                      // the top of the octree: first RT_LDS_NODES DNodes (breadth-first order)
+    __shared__ uint4 s_top[CONT ? 1 : RT_LDS_NODES * 4];           // the top of the octree: first RT_LDS_NODES DNodes (breadth-first order)
     __shared__ unsigned long long s_lmask[RT_WAVES * RT_LEAF_SLOTS];
     __shared__ uint32_t s_lnode[RT_WAVES * RT_LEAF_SLOTS];
+    __shared__ float4 s_tri[RT_WAVES * RT_SHAFT_TRI_REC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, nullptr};
-    const uint32_t n_lds = S.n_nodes < RT_LDS_NODES ? S.n_nodes : RT_LDS_NODES;
-    {
+    const uint32_t n_lds = CONT ? 0u : (S.n_nodes < RT_LDS_NODES ? S.n_nodes : RT_LDS_NODES);
+    if (!CONT) {
         const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(nodes);
         for (uint32_t i = threadIdx.x; i < n_lds * 4u; i += blockDim.x) s_top[i] = src[i];
         __syncthreads();
     }
-    ShaftLds sl{reinterpret_cast<const DNode *>(s_top), n_lds, s_lnode + wave * RT_LEAF_SLOTS, s_lmask + wave * RT_LEAF_SLOTS
+    ShaftLds sl{reinterpret_cast<const DNode *>(s_top), n_lds, s_lnode + wave * RT_LEAF_SLOTS, s_lmask + wave * RT_LEAF_SLOTS, s_tri + wave * RT_SHAFT_TRI_REC
 #ifdef RT_PROFILE
                 , nullptr
 #endif
@@ -1857,20 +1966,37 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
     const float fj_lane = blocks ? static_cast<float>(static_cast<uint32_t>(lane) & 7u) : static_cast<float>(static_cast<uint32_t>(lane) % vst);
     uint32_t c_rays = 0;
     ShardedQueue q;
-    q.init(ctl->queue[ctr_slot], units, gridDim.x * RT_WAVES, blockIdx.x, lane, S.queue_local >= 0 ? static_cast<uint32_t>(S.queue_local) : (P > 1u ? 2u : 0u),
-           static_cast<uint32_t>(S.queue_div));
+    ShardMap tmap{0u, 0u, 0u, 0u};
+    if (CONT) {
+        // the leaf-task launch: work = the chunk-range tasks the walking launch emitted (sharded queue, Control::n_task_sh)
+        tmap = shard_map(ctl->n_task_sh[level], lane, Q.cap / RT_LIST_SHARDS, 1u, 1u);
+        q.init_static(tmap.total, gridDim.x * RT_WAVES, uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave)), lane);
+    } else {
+        q.init(ctl->queue[ctr_slot], units, gridDim.x * RT_WAVES, blockIdx.x, lane, S.queue_local >= 0 ? static_cast<uint32_t>(S.queue_local) : (P > 1u ? 2u : 0u),
+               static_cast<uint32_t>(S.queue_div));
+    }
 #ifdef RT_PROFILE
     PhaseClock pclk; pclk.start();
     sl.pc = &pclk;
     const unsigned long long wave_t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
     if (lane == 0 && g_prof) atomicMin(&g_prof[100], wave_t0 + 1ull);           // (memset 0 = unset: see the host side)
 #endif
-    for (uint32_t unit = 0; q.next(unit);) {
+    for (uint32_t work = 0; q.next(work);) {
 #ifdef RT_PROFILE
         pclk.to(6);
         const unsigned long long unit_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
         RT_PROF_ADD(lane, 13, 1);
+        uint32_t unit = work;
+        uint32_t t_node = 0u, t_cb = 0u, t_ce = 0u;
+        unsigned long long t_mask = 0ull;
+        if (CONT) {
+            uint32_t tsh, tloc, tn;
+            shard_find(tmap, work, tsh, tloc, tn);
+            const ContTask task = Q.tasks_in[tsh * (Q.cap / RT_LIST_SHARDS) + tloc];
+            unit = uniform_u32(task.unit); t_node = uniform_u32(task.node); t_mask = uniform_u64(task.mask);
+            t_cb = uniform_u32(task.c_begin); t_ce = uniform_u32(task.c_end);
+        }
         uint32_t sh, lu, n_sh;
         shard_find(imap, unit, sh, lu, n_sh);
         const uint32_t g = P == 1u ? lu : udiv(lu, P, inv_P), pass = lu - g * P;                       // (hit, light) pair of the list shard, pass of it
@@ -1909,9 +2035,11 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         const float ddx = hx - sx, ddy = hy - sy, ddz = hz - sz;
         const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
         const unsigned long long vis_index = (static_cast<unsigned long long>(g) + static_cast<unsigned long long>(sh) * item_cap * static_cast<unsigned long long>(lslots)) * P + pass;
-        c_rays += valid ? 1u : 0u;
-        const bool sroot = valid && box_hit_verified(root.bmin, sx, sy, sz, ddx, ddy, ddz, srx, sry, srz);
+        if (!CONT) c_rays += valid ? 1u : 0u;
         ShaftLanes SL = make_shaft_lanes(lane, hx, hy, hz, fminf(x0, x1), fminf(y0, y1), fminf(z0, z1), fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1), S.extent);
+        __builtin_amdgcn_wave_barrier();
+        shaft_tri_store(sl.tri, lane, SL, hx, hy, hz, fminf(x0, x1), fminf(y0, y1), fminf(z0, z1), fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1));
+        __builtin_amdgcn_wave_barrier();
         SL.node_ok = __ballot(valid && !(fabsf(ddx) > 0.0f && fabsf(ddy) > 0.0f && fabsf(ddz) > 0.0f && fabsf(ddx) + fabsf(ddy) + fabsf(ddz) < 3e38f)) == 0ull;
         const RayLane R{sx, sy, sz, ddx, ddy, ddz, srx, sry, srz, 4e-4f * (fabsf(sx) + fabsf(sy) + fabsf(sz) + S.extent)};
         bool occ = false;
@@ -1919,15 +2047,29 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         pclk.to(0);
 #endif
         // leaf tasks only pay when the launch has few units per wave (k_shadow has the numbers)
-        const bool tasks_on = Q.tasks_out != nullptr && Q.budget != 0u && units < 256u * gridDim.x * RT_WAVES;
+        const bool tasks_on = TASKS && Q.tasks_out != nullptr && Q.budget != 0u && units < 256u * gridDim.x * RT_WAVES;
         const uint32_t tsh = blockIdx.x & (RT_LIST_SHARDS - 1u), tcap = Q.cap / RT_LIST_SHARDS;          // sharded task queue (Control::n_task_sh)
-        const ShaftTasks TQ{Q.tasks_out + tsh * tcap, &ctl->n_task_sh[level][tsh * 16u], tcap, tasks_on ? Q.budget : 0u, Q.target ? Q.target : Q.budget, unit};
-        shaft_walk(nodes, tris, chunks, stk, sl, lane, root, sroot, R, srx, sry, srz, SL, TQ, occ);
+        if (CONT) {
+            // one chunk range of one big leaf for the rays that reached it; rays another piece already found occluded are dropped
+            const ShaftTasks TQ{nullptr, nullptr, 0u, 0u, 0u, unit};
+            const unsigned long long live = t_mask & uniform_u64(vis[vis_index]);
+            if (live != 0ull) {
+                const DNode leaf = nodes[t_node];
+                shaft_leaf<false>(t_node, uniform_u32(leaf.first), uniform_u32(leaf.count_flags) & 0x7fffffffu, uniform_u32(leaf.pad[0]), tris, chunks, lane, R, SL, TQ,
+                           sl, t_cb, t_ce, live, occ);
+            }
+            const unsigned long long om = __ballot(valid && occ);
+            if (lane == 0 && om != 0ull) atomicAnd(&vis[vis_index], ~om);
+        } else {
+            const bool sroot = valid && box_hit_verified(root.bmin, sx, sy, sz, ddx, ddy, ddz, srx, sry, srz);
+            const ShaftTasks TQ{Q.tasks_out + tsh * tcap, &ctl->n_task_sh[level][tsh * 16u], tcap, tasks_on ? Q.budget : 0u, Q.target ? Q.target : Q.budget, unit};
+            shaft_walk<TASKS>(nodes, tris, chunks, stk, sl, lane, root, sroot, R, srx, sry, srz, SL, TQ, occ);
+            const unsigned long long vm = __ballot(valid && !occ);
+            if (lane == 0) vis[vis_index] = vm;
+        }
 #ifdef RT_PROFILE
         pclk.to(7);
 #endif
-        const unsigned long long vm = __ballot(valid && !occ);
-        if (lane == 0) vis[vis_index] = vm;
 #ifdef RT_PROFILE
         if (lane == 0 && g_prof) {      // per-unit duration histogram: prof[560 + log2(10 ns ticks)], max prof[559]
             const unsigned long long tu = __builtin_amdgcn_s_memrealtime();
@@ -2374,7 +2516,7 @@ void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow
         *trace_primary = q(k_stage<true, false, 0, false>, RT_WAVES * 64, 4);
         *trace_rays = q(k_stage<false, false, 0, false>, RT_WAVES * 64, 4);
         *shadow = q(k_shadow<false, false, false>, RT_WAVES * 64, 4);
-        const int shaft = q(k_shadow_shaft, RT_WAVES * 64, 4);
+        const int shaft = q((k_shadow_shaft<false, false>), RT_WAVES * 64, 4);
         if (shaft < *shadow) *shadow = shaft;
     }
     *shade = q(k_shade, 256, 2);
@@ -2435,7 +2577,18 @@ void launch_shadow(bool count, bool flat, int grid, hipStream_t st, const DScene
 void launch_shadow_shaft(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots, uint32_t item_cap,
                          const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target) {
     const TaskQueues Q{nullptr, tasks_out, 0u, 2u, cap, budget, target};
-    hipLaunchKernelGGL(k_shadow_shaft, dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S, L, level, slot, lslots, item_cap, items, ctl, vis, Q);
+    // (the task emission costs the walking kernel 30 more spilled registers: it is compiled in only when a budget asks for it)
+    if (budget != 0u && tasks_out != nullptr)
+        hipLaunchKernelGGL((k_shadow_shaft<false, true>), dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S, L, level, slot, lslots, item_cap, items, ctl, vis, Q);
+    else
+        hipLaunchKernelGGL((k_shadow_shaft<false, false>), dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S, L, level, slot, lslots, item_cap, items, ctl, vis, Q);
+}
+
+// the leaf tasks of a shaft-walk launch: chunk ranges of big leaves, through the same leaf code (shaft_leaf)
+void launch_shadow_shaft_cont(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, uint32_t item_cap, const ShadeItem *items,
+                              Control *ctl, unsigned long long *vis, const ContTask *tasks_in, uint32_t cap) {
+    const TaskQueues Q{tasks_in, nullptr, 2u, 0u, cap, 0u};
+    hipLaunchKernelGGL((k_shadow_shaft<true, false>), dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S, L, level, 0, lslots, item_cap, items, ctl, vis, Q);
 }
 
 // processes the leaf tasks of queue q_in (leaf tasks never create new tasks)
