@@ -78,6 +78,7 @@ struct rt_ctx {
     uint32_t task_cap = 1u << 21;
     uint32_t trace_budget = 1000u;              // leaves above this estimated cost (VALU instructions) become tasks (0 = off)
     uint32_t shadow_budget = 3000u;
+    int shaft_min_samples = 33;           // tree scenes: sample counts from which a (hit, light) pair gets a wave of its own (k_shadow_shaft)
     uint32_t shaft_budget = 0u;           // the shaft walk culls per triangle: its leaves are cheap enough to stay inline (dodge 1080p: 1.31 -> 1.22 ms without tasks)
     int stage_mult = 2;                         // grid multiplier of the main k_stage launches (RT_STAGE_MULT): twice the resident grid lets
                                                 // blocks of sky tiles retire early and evens out the object tiles (dodge trace 0.278 -> 0.254 ms)
@@ -141,6 +142,7 @@ extern "C" rt_status rt_create(rt_ctx **out, int device) {
     if (const char *dt = std::getenv("RT_TRACE_DYNAMIC")) c->dyn_trace = std::atoi(dt) != 0;
     if (const char *sb = std::getenv("RT_SHADOW_BUDGET")) c->shadow_budget = static_cast<uint32_t>(std::atoi(sb));
     if (const char *sb = std::getenv("RT_SHAFT_BUDGET")) c->shaft_budget = static_cast<uint32_t>(std::atoi(sb));
+    if (const char *sm = std::getenv("RT_SHAFT_MIN_SAMPLES")) c->shaft_min_samples = std::atoi(sm);
     if (const char *sg = std::getenv("RT_STAGED_TRACE")) c->staged_trace = std::atoi(sg) != 0;
     if (const char *sm = std::getenv("RT_STAGE_MULT")) { const int v = std::atoi(sm); if (v >= 1 && v <= 8) c->stage_mult = v; }
     if (const char *tc = std::getenv("RT_TASK_CAP")) { const long v = std::atol(tc); if (v >= 64 && v <= (1l << 24)) c->task_cap = static_cast<uint32_t>(v); }
@@ -652,7 +654,7 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
         launch_set_prof(st, c->d_ctl, RT_WORK_SHADOW);
         // tree scenes with one (hit, light) pair per wave (N > 32 samples): the shaft walk (rt_kernels.hip, k_shadow_shaft)
-        const bool shaft = !c->flat && !count && c->S.shaft != 0 && L.n_samples > 32;
+        const bool shaft = !c->flat && !count && c->S.shaft != 0 && L.n_samples >= c->shaft_min_samples;
         if (shaft)
             launch_shadow_shaft(c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis,
                                 c->d_tasks[0], c->task_cap, c->shaft_budget, c->task_target);

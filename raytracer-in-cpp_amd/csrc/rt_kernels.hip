@@ -1195,6 +1195,7 @@ __device__ __forceinline__ void shaft_walk(const DNode *__restrict__ nodes, cons
             // other waves of the SIMD already cover that latency), 2x / 4x / 8x larger k_stage grids (0 %).
             const DNode nd = (base + gcnt <= sl.n_lds) ? sl.nodes[base + static_cast<uint32_t>(j)] : node_from_lane(ch, 8 * j);
             bool h = ((gm >> lane) & 1ull) != 0ull && !occluded;
+            RT_PROF_ADD(lane, 74, __popcll(__ballot(h)));
             if (nd.pad[1] == 0u) {   // per-ray content test (as packet_walk): no countable point of the segment inside the subtree's content box
                 const float t0x = (nd.clo[0] - R.slab_pad - ox) * R.idx, t1x = (nd.chi[0] + R.slab_pad - ox) * R.idx;
                 const float t0y = (nd.clo[1] - R.slab_pad - oy) * R.idy, t1y = (nd.chi[1] + R.slab_pad - oy) * R.idy;
@@ -1208,7 +1209,7 @@ __device__ __forceinline__ void shaft_walk(const DNode *__restrict__ nodes, cons
             h = h && box_hit_verified(nd.bmin, ox, oy, oz, R.dx, R.dy, R.dz, brx, bry, brz);     // BoundingBox::boxIntersect, exact
             const unsigned long long hm = __ballot(h);
             if (hm == 0ull) continue;
-            RT_PROF_ADD(lane, 91, 1);
+            RT_PROF_ADD(lane, 91, 1); RT_PROF_ADD(lane, 75, __popcll(hm));
             const uint32_t cj = base + static_cast<uint32_t>(j);
             if (nd.count_flags & RT_NODE_LEAF) {
                 if ((nd.count_flags & 0x7fffffffu) == 0u) continue;
