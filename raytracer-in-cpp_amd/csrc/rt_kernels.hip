@@ -848,6 +848,20 @@ __device__ __forceinline__ bool ballot_byte_any(const unsigned long long b, cons
     return ((b >> ((lane & 7) * 8)) & 0xffull) != 0ull;
 }
 
+// The lanes' coefficients are parked in LDS between uses (8 records of 8 floats per wave, written by lanes 0-7 once per unit): they are
+// needed once per group and once per 8 chunk bounds, and eight registers held across the whole walk were eight registers spilled.
+struct ShaftCtl { float pad; bool node_ok; };
+__device__ __forceinline__ void shaft_lanes_store(float4 *lds, const int lane, const ShaftLanes &SL) {
+    if (lane < 8) { lds[2 * lane] = make_float4(SL.r[0], SL.r[1], SL.r[2], SL.r[3]); lds[2 * lane + 1] = make_float4(SL.r[4], SL.r[5], SL.r[6], SL.r[7]); }
+}
+__device__ __forceinline__ ShaftLanes shaft_lanes_load(const float4 *lds, const int tk, const ShaftCtl &SC) {
+    const float4 a = lds[2 * tk], b = lds[2 * tk + 1];
+    ShaftLanes SL;
+    SL.r[0] = a.x; SL.r[1] = a.y; SL.r[2] = a.z; SL.r[3] = a.w; SL.r[4] = b.x; SL.r[5] = b.y; SL.r[6] = b.z; SL.r[7] = b.w;
+    SL.pad = SC.pad; SL.node_ok = SC.node_ok;
+    return SL;
+}
+
 // ---- lane = triangle: one 64-triangle chunk against the unit's shaft --------------------------------------------------------------
 // A counted hit of triangle T (0.00001 < t < 0.98 and the barycentric test of rayTriangleIntersection passed IN FLOAT) has its computed
 // point within ChunkBound::infl (per axis) of T itself (rt_capi.cpp: build_chunk_bounds -- the chunk box is the union of exactly these
@@ -909,6 +923,7 @@ struct ShaftLds {
     uint32_t *lnode;               // per-wave leaf list (RT_LEAF_SLOTS)
     unsigned long long *lmask;
     float4 *tri;                   // per-wave shaft record of the lane = triangle test (RT_SHAFT_TRI_REC)
+    float4 *shaft;                 // per-wave copy of the lanes' coefficients (16 float4: ShaftLanes::r of test tk at [2 tk], [2 tk + 1])
 #ifdef RT_PROFILE
     PhaseClock *pc;
 #endif
@@ -925,7 +940,7 @@ struct ShaftTasks {
 
 template <bool TASKS>
 __device__ __forceinline__ void shaft_leaf(const uint32_t ni, const uint32_t first, const uint32_t cnt, const uint32_t chunk0, const TriRec *__restrict__ tris,
-                                           const ChunkBound *__restrict__ chunks, const int lane, const RayLane &R, const ShaftLanes &SL, const ShaftTasks &TQ,
+                                           const ChunkBound *__restrict__ chunks, const int lane, const RayLane &R, const ShaftCtl &SC, const ShaftTasks &TQ,
                                            const ShaftLds &sl, const uint32_t c_begin, const uint32_t c_end, unsigned long long live, bool &occluded) {
     const float4 *__restrict__ srec = sl.tri;
     const float ox = R.ox, oy = R.oy, oz = R.oz, dx = R.dx, dy = R.dy, dz = R.dz;
@@ -990,6 +1005,8 @@ __device__ __forceinline__ void shaft_leaf(const uint32_t ni, const uint32_t fir
         const uint32_t myc = cb0 + static_cast<uint32_t>(tc);
         const ChunkBound bd = cbounds[myc < nchunk ? myc : cb0];
         bool near_out, far_out;
+        __builtin_amdgcn_wave_barrier();
+        const ShaftLanes SL = shaft_lanes_load(sl.shaft, tk, SC);
         shaft_lane_test(SL, tk, bd.lo[0] - SL.pad, bd.lo[1] - SL.pad, bd.lo[2] - SL.pad, bd.hi[0] + SL.pad, bd.hi[1] + SL.pad, bd.hi[2] + SL.pad, near_out, far_out);
         const unsigned long long b_out = __ballot(near_out && bd.never < 1.5f);
         const uint32_t nhere = nchunk - cb0 < 8u ? nchunk - cb0 : 8u;
@@ -1132,7 +1149,7 @@ __device__ __forceinline__ DNode node_from_lane(const DNode &mine, const int j) 
 template <bool TASKS>
 __device__ __forceinline__ void shaft_walk(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris, const ChunkBound *__restrict__ chunks,
                                            const WaveStack stk, const ShaftLds sl, const int lane, const DNode &root, const bool in_root,
-                                           const RayLane &R, const float brx, const float bry, const float brz, const ShaftLanes &SL, const ShaftTasks &TQ, bool &occluded) {
+                                           const RayLane &R, const float brx, const float bry, const float brz, const ShaftCtl &SC, const ShaftTasks &TQ, bool &occluded) {
     const float ox = R.ox, oy = R.oy, oz = R.oz;
     const unsigned long long m0 = __ballot(in_root);
     if (m0 == 0ull) return;
@@ -1159,7 +1176,7 @@ __device__ __forceinline__ void shaft_walk(const DNode *__restrict__ nodes, cons
                 uint32_t lf, lc, l0;
                 if (li < sl.n_lds) { lf = sl.nodes[li].first; lc = sl.nodes[li].count_flags; l0 = sl.nodes[li].pad[0]; }
                 else { lf = nodes[li].first; lc = nodes[li].count_flags; l0 = nodes[li].pad[0]; }
-                shaft_leaf<TASKS>(li, uniform_u32(lf), uniform_u32(lc) & 0x7fffffffu, uniform_u32(l0), tris, chunks, lane, R, SL, TQ, sl, 0u, 0xffffffffu, lm, occluded);
+                shaft_leaf<TASKS>(li, uniform_u32(lf), uniform_u32(lc) & 0x7fffffffu, uniform_u32(l0), tris, chunks, lane, R, SC, TQ, sl, 0u, 0xffffffffu, lm, occluded);
             }
             nleaf = 0;
             continue;
@@ -1175,9 +1192,11 @@ __device__ __forceinline__ void shaft_walk(const DNode *__restrict__ nodes, cons
         // lane = (child tc, test tk): the child's record, then this lane's separating test on its content box and on its own box
         const uint32_t ci = base + (static_cast<uint32_t>(tc) < gcnt ? static_cast<uint32_t>(tc) : 0u);
         DNode ch;
-        if (base + gcnt <= sl.n_lds) ch = sl.nodes[ci];
+        const bool resident = base + gcnt <= sl.n_lds;
+        if (resident) ch = sl.nodes[ci];
         else ch = nodes[ci];
         bool c_near, c_far, n_near, n_far;
+        const ShaftLanes SL = shaft_lanes_load(sl.shaft, tk, SC);
         shaft_lane_test(SL, tk, ch.clo[0] - SL.pad, ch.clo[1] - SL.pad, ch.clo[2] - SL.pad, ch.chi[0] + SL.pad, ch.chi[1] + SL.pad, ch.chi[2] + SL.pad, c_near, c_far);
         shaft_lane_test(SL, tk, ch.bmin[0] - SL.pad, ch.bmin[1] - SL.pad, ch.bmin[2] - SL.pad, ch.bmax[0] + SL.pad, ch.bmax[1] + SL.pad, ch.bmax[2] + SL.pad, n_near, n_far);
         const unsigned long long b_c = __ballot(c_near && ch.pad[1] == 0u), b_nn = __ballot(n_near), b_nf = __ballot(n_far);
@@ -1192,8 +1211,9 @@ __device__ __forceinline__ void shaft_walk(const DNode *__restrict__ nodes, cons
             // tree (4 ds_read_b128), else 16 v_readlane from the lane that loaded it (cfg4: -2.5 % on k_shadow_shaft).  Measured and
             // rejected here: skipping the per-ray content test on inner nodes (+8 % on cfg4), prefetching the next unit's item with a
             // scalar load (+4 %: 16 more live SGPRs -> spills) or through one VGPR with the queue looking one unit ahead (+6 %: the
-            // other waves of the SIMD already cover that latency), 2x / 4x / 8x larger k_stage grids (0 %).
-            const DNode nd = (base + gcnt <= sl.n_lds) ? sl.nodes[base + static_cast<uint32_t>(j)] : node_from_lane(ch, 8 * j);
+            // other waves of the SIMD already cover that latency), the records of non-resident groups through an LDS slot instead of
+            // v_readlane (+1.5 % on cfg4), 2x / 4x / 8x larger k_stage grids (0 %).
+            const DNode nd = resident ? sl.nodes[base + static_cast<uint32_t>(j)] : node_from_lane(ch, 8 * j);
             bool h = ((gm >> lane) & 1ull) != 0ull && !occluded;
             RT_PROF_ADD(lane, 74, __popcll(__ballot(h)));
             if (nd.pad[1] == 0u) {   // per-ray content test (as packet_walk): no countable point of the segment inside the subtree's content box
@@ -1928,6 +1948,7 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
     __shared__ unsigned long long s_lmask[RT_WAVES * RT_LEAF_SLOTS];
     __shared__ uint32_t s_lnode[RT_WAVES * RT_LEAF_SLOTS];
     __shared__ float4 s_tri[RT_WAVES * RT_SHAFT_TRI_REC];
+    __shared__ float4 s_shaft[RT_WAVES * 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, nullptr};
     const uint32_t n_lds = CONT ? 0u : (S.n_nodes < RT_LDS_NODES ? S.n_nodes : RT_LDS_NODES);
@@ -1936,7 +1957,7 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         for (uint32_t i = threadIdx.x; i < n_lds * 4u; i += blockDim.x) s_top[i] = src[i];
         __syncthreads();
     }
-    ShaftLds sl{reinterpret_cast<const DNode *>(s_top), n_lds, s_lnode + wave * RT_LEAF_SLOTS, s_lmask + wave * RT_LEAF_SLOTS, s_tri + wave * RT_SHAFT_TRI_REC
+    ShaftLds sl{reinterpret_cast<const DNode *>(s_top), n_lds, s_lnode + wave * RT_LEAF_SLOTS, s_lmask + wave * RT_LEAF_SLOTS, s_tri + wave * RT_SHAFT_TRI_REC, s_shaft + wave * 16
 #ifdef RT_PROFILE
                 , nullptr
 #endif
@@ -2040,8 +2061,10 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         ShaftLanes SL = make_shaft_lanes(lane, hx, hy, hz, fminf(x0, x1), fminf(y0, y1), fminf(z0, z1), fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1), S.extent);
         __builtin_amdgcn_wave_barrier();
         shaft_tri_store(sl.tri, lane, SL, hx, hy, hz, fminf(x0, x1), fminf(y0, y1), fminf(z0, z1), fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1));
+        shaft_lanes_store(sl.shaft, lane, SL);
         __builtin_amdgcn_wave_barrier();
-        SL.node_ok = __ballot(valid && !(fabsf(ddx) > 0.0f && fabsf(ddy) > 0.0f && fabsf(ddz) > 0.0f && fabsf(ddx) + fabsf(ddy) + fabsf(ddz) < 3e38f)) == 0ull;
+        ShaftCtl SC{SL.pad, true};
+        SC.node_ok = __ballot(valid && !(fabsf(ddx) > 0.0f && fabsf(ddy) > 0.0f && fabsf(ddz) > 0.0f && fabsf(ddx) + fabsf(ddy) + fabsf(ddz) < 3e38f)) == 0ull;
         const RayLane R{sx, sy, sz, ddx, ddy, ddz, srx, sry, srz, 4e-4f * (fabsf(sx) + fabsf(sy) + fabsf(sz) + S.extent)};
         bool occ = false;
 #ifdef RT_PROFILE
@@ -2056,7 +2079,7 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
             const unsigned long long live = t_mask & uniform_u64(vis[vis_index]);
             if (live != 0ull) {
                 const DNode leaf = nodes[t_node];
-                shaft_leaf<false>(t_node, uniform_u32(leaf.first), uniform_u32(leaf.count_flags) & 0x7fffffffu, uniform_u32(leaf.pad[0]), tris, chunks, lane, R, SL, TQ,
+                shaft_leaf<false>(t_node, uniform_u32(leaf.first), uniform_u32(leaf.count_flags) & 0x7fffffffu, uniform_u32(leaf.pad[0]), tris, chunks, lane, R, SC, TQ,
                            sl, t_cb, t_ce, live, occ);
             }
             const unsigned long long om = __ballot(valid && occ);
@@ -2064,7 +2087,7 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         } else {
             const bool sroot = valid && box_hit_verified(root.bmin, sx, sy, sz, ddx, ddy, ddz, srx, sry, srz);
             const ShaftTasks TQ{Q.tasks_out + tsh * tcap, &ctl->n_task_sh[level][tsh * 16u], tcap, tasks_on ? Q.budget : 0u, Q.target ? Q.target : Q.budget, unit};
-            shaft_walk<TASKS>(nodes, tris, chunks, stk, sl, lane, root, sroot, R, srx, sry, srz, SL, TQ, occ);
+            shaft_walk<TASKS>(nodes, tris, chunks, stk, sl, lane, root, sroot, R, srx, sry, srz, SC, TQ, occ);
             const unsigned long long vm = __ballot(valid && !occ);
             if (lane == 0) vis[vis_index] = vm;
         }
