@@ -204,7 +204,7 @@ def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, c
 
     # ---- executed work of this frame -> modelled VALU issue
     work = work_counters(pkg, hs, W, H, G, D) if want_work else None
-    roof = {"bound": "valu", "kernel": "k_shadow (area-light sample shadow rays" + ("; shaft walk + leaf-task launch)" if shaft else ")"),
+    roof = {"bound": "valu", "kernel": "k_shadow (area-light sample shadow rays" + ("; shaft walk)" if shaft else ")"),
             "unit": "wave-instructions/SIMD/ns", "peak": VALU_PEAK_PER_SIMD_NS,
             "peak_source": "tools/micro/valu_rate.hip on MI355X: plain FP32 wave64 ops, 8 waves/SIMD (spec: 0.5/cycle = 1.2/ns at 2.4 GHz)"}
     if work:
@@ -229,8 +229,9 @@ def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, c
     ent, why = pmc_constant("traffic.json", scene, cfg, sha)
     if ent:
         roof["traffic"] = ent["hbm_bytes_per_launch"]
-        roof["hbm_frac"] = round(ent["hbm_bytes_per_launch"] / (avg_ms_shadow * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-        roof["traffic_source"] = "constant: " + ent["how"]
+        # bytes of the heaviest (level-0) launch over the shadow time of the WHOLE frame (all levels): a lower bound of that launch's rate
+        roof["hbm_frac"] = round(ent["hbm_bytes_per_launch"] / (ms_shadow_frame * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        roof["traffic_source"] = "constant (level-0 launch; divided by the frame's shadow time over all levels): " + ent["how"]
     else:
         roof["traffic"] = None
         roof["hbm_frac"] = None

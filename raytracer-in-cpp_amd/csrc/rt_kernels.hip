@@ -295,14 +295,24 @@ struct WalkCtl {
     uint32_t target;                  // estimated cost of one task piece
     uint32_t task_cap;
     SegPacket seg;                    // shadow units: plane culling (off for every other kind of packet)
+    const float4 *cone;               // per-wave LDS record of the packet's cone (common origin, box of the ray targets): the lane = triangle test of the leaves; nullptr = none
+    bool cone_box;                    // counted hits lie before the targets (t < 0.98: light-centre segments): the AABB of hull(origin, targets) bounds them too
 #ifdef RT_PROFILE
     PhaseClock *pc;
 #endif
 };
+// (defined with the shaft code below)
+__device__ __forceinline__ bool tri_outside_cone(const float4 *rec, const TriRec &tr, const float m, const bool use_box);
+#ifndef RT_TRI_SHAFT_MIN
+#define RT_TRI_SHAFT_MIN 8            // live rays on a chunk from which the per-triangle test (~3 triangle steps) is run
+#endif
+#ifndef RT_RAYMODE_EXTRA
+#define RT_RAYMODE_EXTRA 8u          // scalar loads of the survivors' records
+#endif
 #ifdef RT_PROFILE
-__device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, 0u, 0u, nullptr, nullptr, 1u, 0u, seg_off(), nullptr}; }
+__device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, 0u, 0u, nullptr, nullptr, 1u, 0u, seg_off(), nullptr, false, nullptr}; }
 #else
-__device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, 0u, 0u, nullptr, nullptr, 1u, 0u, seg_off()}; }
+__device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, 0u, 0u, nullptr, nullptr, 1u, 0u, seg_off(), nullptr, false}; }
 #endif
 
 __device__ __forceinline__ TriRec tri_from_regs(const u32x16 &lo, const u32x4 &hi) {
@@ -449,8 +459,8 @@ __device__ __forceinline__ void leaf_visit(const DNode &nd, const uint32_t ni, c
             // conservative chunk test (lanes = rays): a live ray skips the chunk when no point of its line that a hit could
             // count at lies in the chunk's inflated box (rt_capi.cpp, build_chunk_bounds, has the error analysis)
             unsigned long long todo = live;
+            const ChunkBound bd = cbounds[c0 >> 6];
             {
-                const ChunkBound bd = cbounds[c0 >> 6];
                 if (bd.never < 1.5f) {
                     RT_PROF_ADD(lane, 12, 1);
                     const float t0x = (bd.lo[0] - slab_pad - ox) * idx_, t1x = (bd.hi[0] + slab_pad - ox) * idx_;
@@ -468,6 +478,59 @@ __device__ __forceinline__ void leaf_visit(const DNode &nd, const uint32_t ni, c
                     RT_PROF_ADD(lane, 14, __popcll(culled));
                 }
             }
+            // lane = triangle cone test (packets with a common origin: primary tiles, light-centre segments): the triangles of the chunk that
+            // ANY ray of the packet can hit (tri_outside_cone); few survivors and many rays -> lanes = rays over the survivors
+            bool has_c = has;
+            if (!COUNT && wc.cone != nullptr && static_cast<uint32_t>(__popcll(todo)) >= RT_TRI_SHAFT_MIN && bd.never < 1.5f) {
+                __builtin_amdgcn_wave_barrier();
+                has_c = has && !tri_outside_cone(wc.cone, tr, bd.infl * 1.0625f, wc.cone_box);
+                unsigned long long tmask = __ballot(has_c);
+                RT_PROF_ADD(lane, 70, 1); RT_PROF_ADD(lane, 71, __popcll(tmask)); RT_PROF_ADD(lane, 72, __popcll(todo)); RT_PROF_ADD(lane, 73, tmask == 0ull ? 1 : 0);
+                if (tmask == 0ull) {
+                    todo = 0ull;
+                } else if (static_cast<uint32_t>(__popcll(tmask)) * (RT_COST_RAY_MODE + RT_RAYMODE_EXTRA) < static_cast<uint32_t>(__popcll(todo)) * RT_COST_TRI_MODE) {
+                    const bool my = ((todo >> lane) & 1ull) != 0ull;
+                    bool occ_r = false;
+                    const TriRec *__restrict__ Tc = T + c0;
+                    auto ray_lane = [&](const TriRec &ta) {
+                        // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 (lanes = rays)
+                        const float dn = dot3(dx, dy, dz, ta.nx, ta.ny, ta.nz);
+                        const float t = (ta.nA - dot3(ox, oy, oz, ta.nx, ta.ny, ta.nz)) / dn;
+                        const float v2x = (ox + t * dx) - ta.ax, v2y = (oy + t * dy) - ta.ay, v2z = (oz + t * dz) - ta.az;
+                        const float d02 = dot3(ta.e0x, ta.e0y, ta.e0z, v2x, v2y, v2z);
+                        const float d12 = dot3(ta.e1x, ta.e1y, ta.e1z, v2x, v2y, v2z);
+                        const float u = (ta.d11 * d02 - ta.d01 * d12) * ta.inv_denom;
+                        const float v = (ta.d00 * d12 - ta.d01 * d02) * ta.inv_denom;
+                        const bool ok = my && !(ANY && (ta.flags & 1u)) && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f);
+                        if (ANY) {
+                            occ_r = occ_r || (ok && t < 0.98f);
+                        } else {
+                            const bool better = ok && (t < best_t || (t == best_t && static_cast<int>(ta.face) < best_f));
+                            best_t = better ? t : best_t;
+                            best_f = better ? static_cast<int>(ta.face) : best_f;
+                        }
+                    };
+                    while (tmask != 0ull) {
+                        const uint32_t j0 = static_cast<uint32_t>(__builtin_ctzll(tmask));
+                        tmask &= tmask - 1ull;
+                        const bool two = tmask != 0ull;
+                        const uint32_t j1 = two ? static_cast<uint32_t>(__builtin_ctzll(tmask)) : j0;
+                        if (two) tmask &= tmask - 1ull;
+                        RT_PROF_ADD(lane, 0, two ? 2 : 1);
+                        TriRec ta, tb;
+                        tri_load_uniform_pair(Tc + j0, Tc + j1, ta, tb);
+                        ray_lane(ta);
+                        ray_lane(tb);                 // (j1 == j0 for an odd tail: the same triangle twice changes nothing)
+                        if (ANY && __ballot(my && !occ_r) == 0ull) break;
+                    }
+                    if (ANY) {
+                        const unsigned long long ob = __ballot(occ_r);
+                        occ_new |= ob;
+                        live &= ~ob;
+                    }
+                    todo = 0ull;
+                }
+            }
             // step 3 (lanes = triangles): full test of the surviving rays, two rays per step for ILP (two independent
             // division chains in flight)
             while (todo != 0ull) {
@@ -476,7 +539,7 @@ __device__ __forceinline__ void leaf_visit(const DNode &nd, const uint32_t ni, c
                 const bool two = todo != 0ull;
                 const int r1 = two ? static_cast<int>(__builtin_ctzll(todo)) : r0;
                 if (two) todo &= todo - 1ull;
-                RT_PROF_ADD(lane, 2, two ? 2 : 1); RT_PROF_ADD(lane, 3, (two ? 2 : 1) * __popcll(__ballot(has)));
+                RT_PROF_ADD(lane, 2, two ? 2 : 1); RT_PROF_ADD(lane, 3, (two ? 2 : 1) * __popcll(__ballot(has_c)));
                 RT_TILE_COUNT(stk, lane, 2, two ? 2 : 1);
                 // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 (same operations as the ray-lane form)
                 float tq[2]; bool inq[2];
@@ -493,7 +556,7 @@ __device__ __forceinline__ void leaf_visit(const DNode &nd, const uint32_t ni, c
                     const float u = (tr.d11 * d02 - tr.d01 * d12) * tr.inv_denom;
                     const float v = (tr.d00 * d12 - tr.d01 * d02) * tr.inv_denom;
                     tq[q] = t;
-                    inq[q] = has && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f);
+                    inq[q] = has_c && (dn != 0) && (u >= 0) && (v >= 0) && (u + v < 1) && (t > 0.00001f);
                 }
                 if (!two) inq[1] = false;
 #pragma unroll
@@ -907,12 +970,34 @@ __device__ __forceinline__ bool tri_outside_shaft(const float4 *rec, const TriRe
     const SegPacket g{true, false, h.x, h.y, h.z, s0.x, s0.y, s0.z, s1.x, s1.y, s1.z, h.w};
     return out || plane_rules_out(g, tr.nx, tr.ny, tr.nz, tr.nA);
 }
-#ifndef RT_RAYMODE_EXTRA
-#define RT_RAYMODE_EXTRA 8u          // scalar loads of the survivors' records
-#endif
-#ifndef RT_TRI_SHAFT_MIN
-#define RT_TRI_SHAFT_MIN 8            // live rays on a chunk from which the per-triangle test (~3 triangle steps) is run
-#endif
+
+// The same test for a packet whose rays share their ORIGIN o (a primary tile: the camera centre; light-centre segments: the light) and
+// run through targets inside a box: every point a ray can reach (any t >= 0) lies in the cone from o through that box, all of it on the
+// non-positive side of the six tangent planes through o -- so a triangle whose vertex boxes are strictly outside one plane is missed by
+// every ray, whatever t.  The near box (AABB of hull(o, targets)) only bounds hits BEFORE the targets: use_box is set for the
+// light-centre segments (counted hits have t < 0.98) and not for closest-hit rays.  The record is the one shaft_tri_store writes with
+// h := o and S := the target box.
+__device__ __forceinline__ bool tri_outside_cone(const float4 *rec, const TriRec &tr, const float m, const bool use_box) {
+    const float bx = tr.ax + tr.e1x, by = tr.ay + tr.e1y, bz = tr.az + tr.e1z;
+    const float cx = tr.ax + tr.e0x, cy = tr.ay + tr.e0y, cz = tr.az + tr.e0z;
+    bool out = false;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        const float4 pl = rec[p];
+        const int proj = p >> 1;
+        const float ua = proj == 1 ? tr.ay : tr.ax, ub = proj == 1 ? by : bx, uc = proj == 1 ? cy : cx;
+        const float va = proj == 2 ? tr.ay : tr.az, vb = proj == 2 ? by : bz, vc = proj == 2 ? cy : cz;
+        const float fa = __builtin_fmaf(pl.x, ua, pl.y * va), fb = __builtin_fmaf(pl.x, ub, pl.y * vb), fc = __builtin_fmaf(pl.x, uc, pl.y * vc);
+        out = out || (fminf(fminf(fa, fb), fc) + (pl.z - m * pl.w) > 0.0f);
+    }
+    if (use_box) {
+        const float4 lo = rec[6], hi = rec[7];
+        out = out || (fminf(fminf(tr.ax, bx), cx) - m > hi.x) || (fmaxf(fmaxf(tr.ax, bx), cx) + m < lo.x)
+                  || (fminf(fminf(tr.ay, by), cy) - m > hi.y) || (fmaxf(fmaxf(tr.ay, by), cy) + m < lo.y)
+                  || (fminf(fminf(tr.az, bz), cz) - m > hi.z) || (fmaxf(fmaxf(tr.az, bz), cz) + m < lo.z);
+    }
+    return out;
+}
 
 #define RT_LEAF_SLOTS 16
 #define RT_COST_TRI_STEP 58u
@@ -1563,8 +1648,10 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
     __shared__ uint4 s_stage[RT_WAVES * RT_STAGE_TRIS * 5];
     __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
     __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
+    __shared__ float4 s_cone[(CONT && STAGE < 2 && !COUNT) ? RT_WAVES * RT_SHAFT_TRI_REC : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const WaveStack stk{s_node + (false ? 0 : wave * RT_STACK), s_mask + (false ? 0 : wave * RT_STACK), s_stage + (false ? 0 : wave * RT_STAGE_TRIS * 5)};
+    float4 *const cone_rec = s_cone + ((CONT && STAGE < 2 && !COUNT) ? wave * RT_SHAFT_TRI_REC : 0);
     ShardMap rmap{0u, 0u, 0u, 0u};
     if (!PRIMARY) rmap = shard_map(ctl->n_rays[level], lane, 0xffffffffu, 1u, 64u);
     const uint32_t ntiles = PRIMARY ? static_cast<uint32_t>(F.tiles_x) * static_cast<uint32_t>(F.tiles_y) : rmap.total;
@@ -1601,6 +1688,23 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
         const int l = STAGE == 1 ? static_cast<int>(unit - tile * static_cast<uint32_t>(lslots)) : 0;
         const TileRay r = tile_ray<PRIMARY>(tile, lane, F, cam, root, rays_in, rmap);
         const size_t ray_slot = static_cast<size_t>(tile) * 64u + static_cast<size_t>(lane);
+        // the packet's cone for the lane = triangle test of its leaves (leaf_visit): common origin (ax, ay, az), box of the targets of the
+        // lanes in `on` (exact wave min / max).  Only the leaf-task launches build it: there every unit is a run of 64-triangle chunks of a big
+        // leaf (cfg4: closest-hit tasks 0.92 -> 0.68 ms, light-centre tasks 0.55 -> 0.48 ms), while on the walking launches the ~200
+        // instructions per tile cost more than the few big leaves they keep inline return (dodge: +7 us on both)
+        auto set_cone = [&](const bool on, const float ax, const float ay, const float az, const float tx, const float ty, const float tz, const bool box) {
+            float lx = on ? tx : 3e38f, ly = on ? ty : 3e38f, lz = on ? tz : 3e38f, hx_ = on ? tx : -3e38f, hy_ = on ? ty : -3e38f, hz_ = on ? tz : -3e38f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64)); lz = fminf(lz, __shfl_xor(lz, o, 64));
+                hx_ = fmaxf(hx_, __shfl_xor(hx_, o, 64)); hy_ = fmaxf(hy_, __shfl_xor(hy_, o, 64)); hz_ = fmaxf(hz_, __shfl_xor(hz_, o, 64));
+            }
+            const ShaftLanes SLc = make_shaft_lanes(lane, ax, ay, az, lx, ly, lz, hx_, hy_, hz_, S.extent);
+            __builtin_amdgcn_wave_barrier();
+            shaft_tri_store(cone_rec, lane, SLc, ax, ay, az, lx, ly, lz, hx_, hy_, hz_);
+            __builtin_amdgcn_wave_barrier();
+            wc.cone = cone_rec; wc.cone_box = box;
+        };
 
         if (STAGE == 0) {
             // ---- closest hit (flyscene.cpp:655-691)
@@ -1613,6 +1717,8 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
                 if (COUNT && in_root) c_box += 1;
                 in_root = in_root && box_hit_verified(root.bmin, r.ox, r.oy, r.oz, bx, by, bz, brx, bry, brz);
             }
+            // (primary tiles: every ray starts at the camera centre and runs through its screen point o + d)
+            if (CONT && PRIMARY && !COUNT && __ballot(in_root) != 0ull) set_cone(r.pre, r.ox, r.oy, r.oz, r.ox + r.dx, r.oy + r.dy, r.oz + r.dz, false);
             float best_t = 3.402823466e+38f;
             int best_f = -1;
             bool dummy = false;
@@ -1649,6 +1755,8 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
                     if (COUNT && act) c_box += 1;
                     sroot = act && box_hit_verified(root.bmin, px, py, pz, sdx, sdy, sdz, srx, sry, srz);
                 }
+                // (every segment starts at the light: one cone per (tile, light) unless the lanes carry lights of their own)
+                if (CONT && !COUNT && __ballot(act && r.lmode != 0u) == 0ull && __ballot(sroot) != 0ull) set_cone(act, L.pos[l][0], L.pos[l][1], L.pos[l][2], hx, hy, hz, true);
                 float t_unused = 0.f; int f_unused = -1;
                 bool occ = false;
                 uint32_t sig_unused = 0u;
