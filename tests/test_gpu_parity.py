@@ -364,12 +364,14 @@ def test_multiple_lights_and_point_mode(rt, oracle, scenes):
         fs.addLight()                                   # camera centre (0,0,2)
         assert len(fs.lights) == 3
         osc = oracle.load_scene(path)
-        for area in (True, False):
+        # 5x5: two (hit, light) pairs per wave (stack walk); 8x8 and 16x16: one pair / one 64-sample block per wave (the shaft walk on the
+        # tree scene, its per-light grid and its unit -> (item, light, pass) arithmetic with three light slots)
+        for area, u in ((True, 5), (False, 5), (True, 8), (True, 16)):
             fs.areaLight, fs.pointLight = (True, False) if area else (True, True)
-            fs.usteps = fs.vsteps = 5
+            fs.usteps = fs.vsteps = u
             fs.max_depth = 3
             rgb = fs.raytraceScene(200, 120, write_ppm=False, want_hits=True, collect_stats=True)
-            L = oracle.lights(area=area, usteps=5, vsteps=5, points=fs.lights)
+            L = oracle.lights(area=area, usteps=u, vsteps=u, points=fs.lights)
             ref, rhits, ost = osc.render(oracle.camera(200, 120), L, 200, 120, max_depth=3, threads=8, want_hits=True)
             assert_frame_parity(oracle, rgb, fs.hits, ref, rhits)
             st = fs.stats
