@@ -295,6 +295,7 @@ struct WalkCtl {
     uint32_t target;                  // estimated cost of one task piece
     uint32_t task_cap;
     SegPacket seg;                    // shadow units: plane culling (off for every other kind of packet)
+    unsigned long long skip;          // flat scenes: triangles of the root leaf that no ray of the unit can hit (bit = position in the leaf)
     const float4 *cone;               // per-wave LDS record of the packet's cone (common origin, box of the ray targets): the lane = triangle test of the leaves; nullptr = none
     bool cone_box;                    // counted hits lie before the targets (t < 0.98: light-centre segments): the AABB of hull(origin, targets) bounds them too
 #ifdef RT_PROFILE
@@ -310,9 +311,9 @@ __device__ __forceinline__ bool tri_outside_cone(const float4 *rec, const TriRec
 #define RT_RAYMODE_EXTRA 8u          // scalar loads of the survivors' records
 #endif
 #ifdef RT_PROFILE
-__device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, 0u, 0u, nullptr, nullptr, 1u, 0u, seg_off(), nullptr, false, nullptr}; }
+__device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, 0u, 0u, nullptr, nullptr, 1u, 0u, seg_off(), 0ull, nullptr, false, nullptr}; }
 #else
-__device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, 0u, 0u, nullptr, nullptr, 1u, 0u, seg_off(), nullptr, false}; }
+__device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, 0u, 0u, nullptr, nullptr, 1u, 0u, seg_off(), 0ull, nullptr, false}; }
 #endif
 
 __device__ __forceinline__ TriRec tri_from_regs(const u32x16 &lo, const u32x4 &hi) {
@@ -737,7 +738,7 @@ __device__ __forceinline__ void packet_walk(const DNode *__restrict__ nodes, con
 // unit then tells which of the root's triangles any of the unit's 64 segments can still be blocked by.
 
 template <bool ANY, bool COUNT>
-__device__ __forceinline__ void flat_walk(const DNode &root, const TriRec *__restrict__ tris, bool in_root, const SegPacket &seg, const LanePlane &pl,
+__device__ __forceinline__ void flat_walk(const DNode &root, const TriRec *__restrict__ tris, bool in_root, const SegPacket &seg, const unsigned long long skip, const LanePlane &pl,
                                           const float ox, const float oy, const float oz,
                                           const float dx, const float dy, const float dz,
                                           float &best_t, int &best_f, bool &occluded, uint32_t &cnt_box, uint32_t &cnt_ref) {
@@ -768,7 +769,7 @@ __device__ __forceinline__ void flat_walk(const DNode &root, const TriRec *__res
     };
     if (ANY && !COUNT && seg.on) {
         // shadow unit: only the triangles whose plane is crossed between a light sample and the hit point
-        unsigned long long keep = cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull);
+        unsigned long long keep = (cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull)) & ~skip;
         keep &= ~__ballot(seg.prepared ? plane_rules_out_prepared(seg, pl) : plane_rules_out(seg, pl.nx, pl.ny, pl.nz, pl.nA));
         RT_PROF_ADD(threadIdx.x & 63, 6, 1); RT_PROF_ADD(threadIdx.x & 63, 1, __popcll(keep));
         while (keep != 0ull) {
@@ -814,7 +815,7 @@ __device__ __forceinline__ void walk(const DNode &root, const DNode *__restrict_
                                      const float brx, const float bry, const float brz,
                                      float &best_t, int &best_f, bool &occluded, uint32_t &cnt_box, uint32_t &cnt_ref) {
     uint32_t sig_unused = 0u;
-    if (FLAT) flat_walk<ANY, COUNT>(root, tris, in_root, wc.seg, pl, ox, oy, oz, dx, dy, dz, best_t, best_f, occluded, cnt_box, cnt_ref);
+    if (FLAT) flat_walk<ANY, COUNT>(root, tris, in_root, wc.seg, wc.skip, pl, ox, oy, oz, dx, dy, dz, best_t, best_f, occluded, cnt_box, cnt_ref);
     else packet_walk<ANY, COUNT, STAGED>(nodes, tris, chunks, leaf_chunk0, extent, stk, lane, wc, in_root, ox, oy, oz, dx, dy, dz, bx, by, bz,
                                  brx, bry, brz, best_t, best_f, occluded, cnt_box, cnt_ref, sig_unused);
 }
@@ -1825,12 +1826,13 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
 #define RT_SHADOW_WPE 5
 #endif
 template <bool COUNT, bool FLAT, bool CONT>
-__global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(RT_SHADOW_WPE, 8))) void k_shadow(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris,
+__global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(FLAT ? 6 : RT_SHADOW_WPE, 8))) void k_shadow(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris,
                                                           const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                                            const DScene S, const DLights L, const int level, const int ctr_slot,
                                                            const int lslots, const uint32_t item_cap, const ShadeItem *__restrict__ items,
                                                            Control *__restrict__ ctl, unsigned long long *vis, const TaskQueues Q) {
     __shared__ uint4 s_stage[1];                                              // k_shadow never stages leaves in LDS (leaf_visit<.., STAGED = false>)
+    __shared__ float4 s_fv[(FLAT && !COUNT) ? 64 * 3 : 1];                    // flat scenes: the vertices A, B, C of the root leaf's triangles
     __shared__ unsigned long long s_mask[FLAT ? 1 : RT_WAVES * RT_STACK];     // flat scenes need no stack
     __shared__ uint32_t s_node[FLAT ? 1 : RT_WAVES * RT_STACK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1856,6 +1858,22 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     if (FLAT && static_cast<uint32_t>(lane) < (root.count_flags & 0x7fffffffu)) {
         const TriRec *tp = tris + root.first + lane;
         plane = LanePlane{tp->nx, tp->ny, tp->nz, tp->nA, 0.f, 0.f};
+    }
+    // Flat scenes, one (hit, light) pair per wave: besides the plane rule, the geometric shaft test of the tree scenes, here with
+    // lane = (triangle, test) -- 8 triangles x (6 tangent planes + near box) per wave step, ceil(count / 8) steps per unit; the vertices
+    // come from LDS (unit-invariant), the margin from the leaf's chunk bound.  cube.obj at 1080p/64: 6.8 -> [see DESIGN] triangles per unit.
+    float flat_m = -1.0f;
+    if (FLAT && !COUNT) {
+        const uint32_t fcnt = root.count_flags & 0x7fffffffu;
+        for (uint32_t i = threadIdx.x; i < fcnt && i < 64u; i += blockDim.x) {
+            const TriRec t = tris[root.first + i];
+            s_fv[3u * i] = make_float4(t.ax, t.ay, t.az, 0.f);
+            s_fv[3u * i + 1u] = make_float4(t.ax + t.e1x, t.ay + t.e1y, t.az + t.e1z, 0.f);
+            s_fv[3u * i + 2u] = make_float4(t.ax + t.e0x, t.ay + t.e0y, t.az + t.e0z, 0.f);
+        }
+        __syncthreads();
+        const ChunkBound cb0 = chunks[root.pad[0]];
+        if (cb0.never < 1.5f && fcnt <= 64u) flat_m = cb0.infl * 1.0625f;
     }
     // (tried on octree leaves too: 25 % fewer ray-mode triangle tests on dodgeColorTest.obj but no whole 64-triangle chunk is ever
     // skipped, and the per-leaf plane pass plus its registers cost more than they saved: 2.31 ms vs 1.93 ms)
@@ -1942,9 +1960,19 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
             }
             valid = s < N;
         }
-        const uint32_t item_i = valid ? (lslots == 1 ? g : g / static_cast<uint32_t>(lslots)) : 0u;
-        const int l = valid ? static_cast<int>(g - item_i * static_cast<uint32_t>(lslots)) : 0;
-        const ShadeItem it = items[sh * item_cap + item_i];
+        uint32_t item_i = valid ? (lslots == 1 ? g : g / static_cast<uint32_t>(lslots)) : 0u;
+        int l = valid ? static_cast<int>(g - item_i * static_cast<uint32_t>(lslots)) : 0;
+        ShadeItem it;
+        if (G == 1u) {
+            // one pair per wave: g is the same in every lane, and so is the item -- a wave-uniform index (scalar load).  Every lane, also
+            // one past the last sample, then carries the unit's h and light: the triangle lanes of the culling tests rely on that.
+            const uint32_t gu = uniform_u32(g);
+            item_i = lslots == 1 ? gu : gu / static_cast<uint32_t>(lslots);
+            l = static_cast<int>(gu - item_i * static_cast<uint32_t>(lslots));
+            it = items[uniform_u32(sh * item_cap + item_i)];
+        } else {
+            it = items[sh * item_cap + item_i];
+        }
         g += sh * item_cap * static_cast<uint32_t>(lslots);               // (item storage index) * lslots + light: the vis slot
         const int nl = it.lmode ? 1 : L.n_lights;
         valid = valid && (l < nl);
@@ -1968,8 +1996,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
                 sphere_box(L, px, py, pz, x0, y0, z0, x1, y1, z1);
             }
         }
-        const float ddx = hx - sx, ddy = hy - sy, ddz = hz - sz;
-        const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
+        const unsigned long long vis_index = N <= 64u ? static_cast<unsigned long long>(g) : static_cast<unsigned long long>(g) * P + pass;
         if (plane_cull) {
             wc.seg.on = true;
             wc.seg.prepared = !own_light;
@@ -1979,7 +2006,47 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
             wc.seg.slz = fminf(z0, z1); wc.seg.shz = fmaxf(z0, z1);
             wc.seg.m0 = 2e-5f * ((fabsf(x0) + fabsf(x1)) + (fabsf(y0) + fabsf(y1)) + (fabsf(z0) + fabsf(z1)) + (fabsf(hx) + fabsf(hy) + fabsf(hz)));
         }
-        const unsigned long long vis_index = N <= 64u ? static_cast<unsigned long long>(g) : static_cast<unsigned long long>(g) * P + pass;
+        if (FLAT && !COUNT && plane_cull && flat_m >= 0.0f) {
+            // Which triangles of the (flat) scene can ANY ray of the unit hit?  Known before a single ray is set up: the geometric shaft
+            // test (lane = (triangle, test)) and the plane rule (lane = triangle) only need h and the box of the samples.
+            const ShaftLanes SLf = make_shaft_lanes(lane, wc.seg.hx, wc.seg.hy, wc.seg.hz, wc.seg.slx, wc.seg.sly, wc.seg.slz, wc.seg.shx, wc.seg.shy, wc.seg.shz, S.extent);
+            const int tk = lane & 7;
+            const float pax = SLf.r[0] + SLf.r[1], pay = SLf.r[2] + SLf.r[3], paz = SLf.r[4] + SLf.r[5];          // (one addend is zero: exact)
+            const float pcm = SLf.r[6] - flat_m * ((fabsf(pax) + fabsf(pay)) + fabsf(paz));
+            const uint32_t fcnt = root.count_flags & 0x7fffffffu;
+            unsigned long long skip = 0ull;
+            for (uint32_t t0 = 0u; t0 < fcnt; t0 += 8u) {
+                const uint32_t t = t0 + (static_cast<uint32_t>(lane) >> 3);
+                const bool tv = t < fcnt;
+                const float4 A = s_fv[3u * (tv ? t : 0u)], B = s_fv[3u * (tv ? t : 0u) + 1u], C = s_fv[3u * (tv ? t : 0u) + 2u];
+                const float fa = __builtin_fmaf(pax, A.x, __builtin_fmaf(pay, A.y, paz * A.z));
+                const float fb = __builtin_fmaf(pax, B.x, __builtin_fmaf(pay, B.y, paz * B.z));
+                const float fc = __builtin_fmaf(pax, C.x, __builtin_fmaf(pay, C.y, paz * C.z));
+                const bool p_out = fminf(fminf(fa, fb), fc) + pcm > 0.0f;
+                const bool b_out = (fminf(fminf(A.x, B.x), C.x) - flat_m > SLf.r[3]) || (fmaxf(fmaxf(A.x, B.x), C.x) + flat_m < SLf.r[0])
+                                || (fminf(fminf(A.y, B.y), C.y) - flat_m > SLf.r[4]) || (fmaxf(fmaxf(A.y, B.y), C.y) + flat_m < SLf.r[1])
+                                || (fminf(fminf(A.z, B.z), C.z) - flat_m > SLf.r[5]) || (fmaxf(fmaxf(A.z, B.z), C.z) + flat_m < SLf.r[2]);
+                const unsigned long long bo = __ballot(tv && (tk < 6 ? p_out : (tk == 6 && b_out)));
+                const unsigned long long m8 = __ballot(lane < 8 && ballot_byte_any(bo, lane)) & 0xffull;
+                skip |= m8 << t0;
+            }
+            skip |= __ballot(wc.seg.prepared ? plane_rules_out_prepared(wc.seg, plane) : plane_rules_out(wc.seg, plane.nx, plane.ny, plane.nz, plane.nA));
+            wc.skip = skip;
+            RT_PROF_ADD(lane, 70, 1); RT_PROF_ADD(lane, 71, __popcll(skip & (fcnt >= 64u ? ~0ull : ((1ull << fcnt) - 1ull))));
+            if (((fcnt >= 64u ? ~0ull : ((1ull << fcnt) - 1ull)) & ~skip) == 0ull) {
+                // nothing in the scene can block any ray of this unit: every sample is visible, whatever the root test of its ray says
+                c_rays += valid ? 1u : 0u;
+                const unsigned long long vm = __ballot(valid);
+                if (N <= 64u) {
+                    if (s_in == 0u && slot_ok) vis[vis_index] = (vm >> (slot * N)) & low;
+                } else if (lane == 0) {
+                    vis[vis_index] = vm;
+                }
+                continue;
+            }
+        }
+        const float ddx = hx - sx, ddy = hy - sy, ddz = hz - sz;
+        const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
         bool sroot;
         if (CONT) {
             // the root test was passed when the task was emitted (the mask only holds lanes that reached `node`); rays
