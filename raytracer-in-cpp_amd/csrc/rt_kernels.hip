@@ -1844,6 +1844,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(F
     const ShardMap imap = N <= 64u ? shard_map(ctl->n_items[level], lane, item_cap, static_cast<uint32_t>(lslots), G)
                                    : shard_map(ctl->n_items[level], lane, item_cap, static_cast<uint32_t>(lslots) * P, 1u);
     const unsigned long long units = imap.total;
+    if (!CONT && units == 0ull) return;           // an empty bounce level: leave before any set-up (every wave takes this branch)
     const DNode root = nodes[0];
     const uint32_t slot = N <= 64u ? static_cast<uint32_t>(lane) / N : 0u;
     const uint32_t s_in = N <= 64u ? static_cast<uint32_t>(lane) - slot * N : static_cast<uint32_t>(lane);
@@ -2127,11 +2128,6 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, nullptr};
     const uint32_t n_lds = CONT ? 0u : (S.n_nodes < RT_LDS_NODES ? S.n_nodes : RT_LDS_NODES);
-    if (!CONT) {
-        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(nodes);
-        for (uint32_t i = threadIdx.x; i < n_lds * 4u; i += blockDim.x) s_top[i] = src[i];
-        __syncthreads();
-    }
     ShaftLds sl{reinterpret_cast<const DNode *>(s_top), n_lds, s_lnode + wave * RT_LEAF_SLOTS, s_lmask + wave * RT_LEAF_SLOTS, s_tri + wave * RT_SHAFT_TRI_REC, s_shaft + wave * 16
 #ifdef RT_PROFILE
                 , nullptr
@@ -2141,6 +2137,12 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
     const uint32_t P = (N + 63u) / 64u;                       // 64-sample passes (= mask words) per pair
     const ShardMap imap = shard_map(ctl->n_items[level], lane, item_cap, static_cast<uint32_t>(lslots) * P, 1u);
     const uint32_t units = imap.total;
+    if (units == 0u) return;                      // an empty bounce level: leave before the LDS copy (every wave of the block takes this branch)
+    if (!CONT) {
+        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(nodes);
+        for (uint32_t i = threadIdx.x; i < n_lds * 4u; i += blockDim.x) s_top[i] = src[i];
+        __syncthreads();
+    }
     const DNode root = nodes[0];
     const uint32_t vst = static_cast<uint32_t>(L.vsteps > 0 ? L.vsteps : 1);
     const bool blocks = sample_blocks(L);
