@@ -60,7 +60,7 @@ COST = {
     "chunk_per_ray": 39,         # per-ray conservative chunk test (7 v_readlane + slab test)
     "tri_shaft_test": 140,       # lane = triangle: 3 vertex boxes against 6 tangent planes + near box + the (t <= 0 or |t| >= 0.98) plane rule
     "unit_shaft": 270,           # k_shadow_shaft per unit: queue, item, sample, root test, shaft planes (make_shaft_lanes ~95), LDS records
-    "unit_flat": 250,            # flat k_shadow per unit: item, sample, root test, plane culling, queue
+    "unit_flat": 355,            # flat k_shadow per unit: queue, item, h, shaft planes (~85), 8 triangles x 8 tests per step (2 x ~45 on the cube), plane rule, visibility word
     "unit_stack": 200,
 }
 

@@ -1862,7 +1862,8 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(F
     }
     // Flat scenes, one (hit, light) pair per wave: besides the plane rule, the geometric shaft test of the tree scenes, here with
     // lane = (triangle, test) -- 8 triangles x (6 tangent planes + near box) per wave step, ceil(count / 8) steps per unit; the vertices
-    // come from LDS (unit-invariant), the margin from the leaf's chunk bound.  cube.obj at 1080p/64: 6.8 -> [see DESIGN] triangles per unit.
+    // come from LDS (unit-invariant), the margin from the leaf's chunk bound.  cube.obj at 1080p/64: 6.8 -> 0.011 triangle tests per
+    // unit (99.8 % of the units keep no triangle at all and leave before a single ray is set up).
     float flat_m = -1.0f;
     if (FLAT && !COUNT) {
         const uint32_t fcnt = root.count_flags & 0x7fffffffu;
