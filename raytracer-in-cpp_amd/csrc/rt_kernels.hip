@@ -1830,7 +1830,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(F
                                                           const ChunkBound *__restrict__ chunks, const uint32_t *__restrict__ leaf_chunk0,
                                                            const DScene S, const DLights L, const int level, const int ctr_slot,
                                                            const int lslots, const uint32_t item_cap, const ShadeItem *__restrict__ items,
-                                                           Control *__restrict__ ctl, unsigned long long *vis, const TaskQueues Q) {
+                                                           Control *__restrict__ ctl, unsigned long long *vis, const TaskQueues Q, const uint32_t *__restrict__ sidx) {
     __shared__ uint4 s_stage[1];                                              // k_shadow never stages leaves in LDS (leaf_visit<.., STAGED = false>)
     __shared__ float4 s_fv[(FLAT && !COUNT) ? 64 * 3 : 1];                    // flat scenes: the vertices A, B, C of the root leaf's triangles
     __shared__ unsigned long long s_mask[FLAT ? 1 : RT_WAVES * RT_STACK];     // flat scenes need no stack
@@ -1841,8 +1841,10 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(F
     const uint32_t G = N <= 64u ? 64u / N : 1u;              // (hit,light) pairs per wave
     const uint32_t P = (N + 63u) / 64u;                       // 64-sample passes (= mask words) per pair
     // units of list shard s: ceil(cnt_s * lslots / G) (N <= 64) or cnt_s * lslots * P (N > 64), numbered shard after shard
-    const ShardMap imap = N <= 64u ? shard_map(ctl->n_items[level], lane, item_cap, static_cast<uint32_t>(lslots), G)
-                                   : shard_map(ctl->n_items[level], lane, item_cap, static_cast<uint32_t>(lslots) * P, 1u);
+    // (after k_beam: the units are the hits of its compacted survivor list)
+    const uint32_t *__restrict__ item_counts = sidx != nullptr ? ctl->n_sitems[level] : ctl->n_items[level];
+    const ShardMap imap = N <= 64u ? shard_map(item_counts, lane, item_cap, static_cast<uint32_t>(lslots), G)
+                                   : shard_map(item_counts, lane, item_cap, static_cast<uint32_t>(lslots) * P, 1u);
     const unsigned long long units = imap.total;
     if (!CONT && units == 0ull) return;           // an empty bounce level: leave before any set-up (every wave takes this branch)
     const DNode root = nodes[0];
@@ -1964,6 +1966,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(F
         }
         uint32_t item_i = valid ? (lslots == 1 ? g : g / static_cast<uint32_t>(lslots)) : 0u;
         int l = valid ? static_cast<int>(g - item_i * static_cast<uint32_t>(lslots)) : 0;
+        uint32_t item_at;
         ShadeItem it;
         if (G == 1u) {
             // one pair per wave: g is the same in every lane, and so is the item -- a wave-uniform index (scalar load).  Every lane, also
@@ -1971,11 +1974,15 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(F
             const uint32_t gu = uniform_u32(g);
             item_i = lslots == 1 ? gu : gu / static_cast<uint32_t>(lslots);
             l = static_cast<int>(gu - item_i * static_cast<uint32_t>(lslots));
-            it = items[uniform_u32(sh * item_cap + item_i)];
+            item_at = uniform_u32(sh * item_cap + item_i);
+            if (sidx != nullptr) item_at = uniform_u32(sidx[item_at]);           // k_beam's survivors: position in the list -> item storage index
+            it = items[item_at];
         } else {
-            it = items[sh * item_cap + item_i];
+            item_at = sh * item_cap + item_i;
+            if (sidx != nullptr) item_at = sidx[item_at];
+            it = items[item_at];
         }
-        g += sh * item_cap * static_cast<uint32_t>(lslots);               // (item storage index) * lslots + light: the vis slot
+        g = item_at * static_cast<uint32_t>(lslots) + static_cast<uint32_t>(l);     // (item storage index) * lslots + light: the vis slot
         const int nl = it.lmode ? 1 : L.n_lights;
         valid = valid && (l < nl);
         const float hx = it.ox + it.t * it.dx, hy = it.oy + it.t * it.dy, hz = it.oz + it.t * it.dz;
@@ -2118,7 +2125,8 @@ template <bool CONT, bool TASKS>
 __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(RT_SHADOW_WPE, 8)))
 void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris, const ChunkBound *__restrict__ chunks,
                     const DScene S, const DLights L, const int level, const int ctr_slot, const int lslots, const uint32_t item_cap,
-                    const ShadeItem *__restrict__ items, Control *__restrict__ ctl, unsigned long long *__restrict__ vis, const TaskQueues Q) {
+                    const ShadeItem *__restrict__ items, Control *__restrict__ ctl, unsigned long long *__restrict__ vis, const TaskQueues Q,
+                    const uint32_t *__restrict__ sidx) {
     __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
     __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
     __shared__ uint4 s_top[CONT ? 1 : RT_LDS_NODES * 4];           // the top of the octree: first RT_LDS_NODES DNodes (breadth-first order)
@@ -2136,7 +2144,7 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
     };
     const uint32_t N = static_cast<uint32_t>(L.n_samples);
     const uint32_t P = (N + 63u) / 64u;                       // 64-sample passes (= mask words) per pair
-    const ShardMap imap = shard_map(ctl->n_items[level], lane, item_cap, static_cast<uint32_t>(lslots) * P, 1u);
+    const ShardMap imap = shard_map(sidx != nullptr ? ctl->n_sitems[level] : ctl->n_items[level], lane, item_cap, static_cast<uint32_t>(lslots) * P, 1u);
     const uint32_t units = imap.total;
     if (units == 0u) return;                      // an empty bounce level: leave before the LDS copy (every wave of the block takes this branch)
     if (!CONT) {
@@ -2202,7 +2210,9 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         const uint32_t g = P == 1u ? lu : udiv(lu, P, inv_P), pass = lu - g * P;                       // (hit, light) pair of the list shard, pass of it
         const uint32_t item_i = lslots == 1 ? g : udiv(g, static_cast<uint32_t>(lslots), inv_ls);
         const int l = static_cast<int>(g - item_i * static_cast<uint32_t>(lslots));
-        const ShadeItem it = items[uniform_u32(sh * item_cap + item_i)];      // wave-uniform: a scalar load
+        uint32_t item_at = uniform_u32(sh * item_cap + item_i);
+        if (sidx != nullptr) item_at = uniform_u32(sidx[item_at]);            // k_beam's survivors: position in the list -> item storage index
+        const ShadeItem it = items[item_at];                                  // wave-uniform: a scalar load
         uint32_t s = pass * 64u + static_cast<uint32_t>(lane);
         float fi = fi_lane + 0.5f, fj = fj_lane + 0.5f;                       // the lane's sample (i + 0.5, j + 0.5) -- P == 1: s = lane
         float b_i0 = 0.5f, b_j0 = 0.5f, b_i1 = fi_last, b_j1 = fj_last;      // grid corners of the unit's samples (the whole light unless in blocks)
@@ -2234,7 +2244,7 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         }
         const float ddx = hx - sx, ddy = hy - sy, ddz = hz - sz;
         const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
-        const unsigned long long vis_index = (static_cast<unsigned long long>(g) + static_cast<unsigned long long>(sh) * item_cap * static_cast<unsigned long long>(lslots)) * P + pass;
+        const unsigned long long vis_index = (static_cast<unsigned long long>(item_at) * static_cast<unsigned long long>(lslots) + static_cast<unsigned long long>(l)) * P + pass;
         if (!CONT) c_rays += valid ? 1u : 0u;
         ShaftLanes SL = make_shaft_lanes(lane, hx, hy, hz, fminf(x0, x1), fminf(y0, y1), fminf(z0, z1), fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1), S.extent);
         __builtin_amdgcn_wave_barrier();
@@ -2305,6 +2315,221 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         atomicAdd(&g_prof[500 + (xcc & 7u)], static_cast<unsigned long long>(c_rays_dbg));
     }
 #endif
+    c_rays = wave_sum(c_rays);
+    if (lane == 0 && c_rays) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_SAMPLE], static_cast<unsigned long long>(c_rays));
+}
+
+// ======================================================================================================
+// K1.5 BEAM TEST -- one wave per tile of 64 consecutive lit hits (a k_shade tile: neighbouring pixels of a primary tile, neighbouring
+// bounce rays), before any sample shadow ray is formed.
+//
+// The sample segments of every hit of the tile to scene light l lie in the BEAM hull(S, H): S the box of the light's samples, H the box
+// of the tile's hit points.  With h_c the centre of H and e its half extent, hull(S, h') is contained in hull(S, h_c) + [-e, e] for
+// every h' in H (the same parameter on the two segments s -> h' and s -> h_c gives points that differ by at most e per axis), so a box or
+// triangle neighbourhood GROWN by e that lies outside the shaft of (S, h_c) is outside the shaft of every hit of the tile.  The shaft
+// tests of the unit walk are therefore reused as they are: the lanes' coefficients are built for h_c and then relaxed by e
+// (shaft_inflate).  The tree is walked by content box only (a counted hit lies in the content box of every ancestor of its leaf and in
+// its chunk box, whatever the reference's own box tests say), chunk bounds, then triangle by triangle; the plane rules take the
+// interval of h.n over H (plane_rules_out_box).  If NO triangle of the scene survives, every sample of every hit of the tile sees the
+// light: the visibility words are written here and the hits never become shadow units.  One surviving triangle, an uncullable chunk or a
+// hit with a light list of its own (mirror bounce) and the items go to the shadow kernels through the compacted index list `sidx`.
+// ======================================================================================================
+// the decision of plane_rules_out for EVERY (s, h), s in the sample box, h in [hlo, hhi]; m0 as there, over both boxes
+__device__ __forceinline__ bool plane_rules_out_box(const float slx, const float sly, const float slz, const float shx, const float shy, const float shz,
+                                                    const float hlx, const float hly, const float hlz, const float hhx, const float hhy, const float hhz,
+                                                    const float m0, const float nx, const float ny, const float nz, const float nA) {
+    const float ax = nx * slx, bx = nx * shx, ay = ny * sly, by = ny * shy, az = nz * slz, bz = nz * shz;
+    const float sn_lo = fminf(ax, bx) + (fminf(ay, by) + fminf(az, bz));
+    const float sn_hi = fmaxf(ax, bx) + (fmaxf(ay, by) + fmaxf(az, bz));
+    const float cx = nx * hlx, dx = nx * hhx, cy = ny * hly, dy = ny * hhy, cz = nz * hlz, dz = nz * hhz;
+    const float hn_lo = fminf(cx, dx) + (fminf(cy, dy) + fminf(cz, dz));
+    const float hn_hi = fmaxf(cx, dx) + (fmaxf(cy, dy) + fmaxf(cz, dz));
+    const float num_lo = nA - sn_hi, num_hi = nA - sn_lo;                 // num = n.A - s.n
+    const float dn_lo = hn_lo - sn_hi, dn_hi = hn_hi - sn_lo;             // dn = (h - s).n, s and h independent
+    const float M = m0 + 2e-5f * fabsf(nA);
+    const bool sane = (fabsf(nx) + fabsf(ny) + fabsf(nz) <= 4.0f) && (fabsf(nA) <= 1e30f);
+    const bool opposite = (num_lo > M && dn_hi < -M) || (num_hi < -M && dn_lo > M);
+    const float min_abs_num = fmaxf(num_lo, -num_hi);              // <= 0 when the interval straddles zero
+    const float max_abs_dn = fmaxf(fabsf(dn_lo), fabsf(dn_hi));
+    const bool beyond = (min_abs_num - M) >= 0.981f * (max_abs_dn + M);
+    // the same s in both: dn = num + e with e = h.n - n.A, so |e| <= 0.018 |num| puts t = num / dn into [0.982, 1.019] -- not counted
+    // (lightStrikes wants t < 0.98).  This is the face the hits lie on and its near-coplanar neighbours, at any light orientation.
+    const float e_max = fmaxf(fabsf(hn_lo - nA), fabsf(hn_hi - nA));
+    const float a_min = min_abs_num - M;
+    const bool near_plane = (a_min > 0.0f) && (e_max + 2.0f * M <= 0.018f * a_min);
+    return sane && (num_lo <= num_hi) && (dn_lo <= dn_hi) && (hn_lo <= hn_hi) && (opposite || beyond || near_plane);
+}
+// relaxes this lane's test by the half extent e of the apex box (see above): a plane value over a box grown by e is lower by
+// sum |a_k| e_k; the near box grows by e.  The far tests are not used by beams.
+__device__ __forceinline__ void shaft_inflate(ShaftLanes &SL, const int tk, const float ex, const float ey, const float ez) {
+    if (tk < 6) {
+        const float ax = SL.r[0] + SL.r[1], ay = SL.r[2] + SL.r[3], az = SL.r[4] + SL.r[5];
+        SL.r[6] = SL.r[6] - ((fabsf(ax) * ex + fabsf(ay) * ey) + fabsf(az) * ez) * 1.0001f;
+    } else if (tk == 6) {
+        SL.r[0] -= ex; SL.r[1] -= ey; SL.r[2] -= ez; SL.r[3] += ex; SL.r[4] += ey; SL.r[5] += ez;
+    }
+}
+#define RT_BEAM_REC 13                 // float4 per wave: shaft_tri_store's 11 (planes, near box, (h_c, m0), S lo, S hi) + H lo, H hi
+
+// lane = triangle: can ANY segment of the beam hit this triangle with a counted t?  (planes and near box from the relaxed record)
+__device__ __forceinline__ bool tri_outside_beam(const float4 *rec, const TriRec &tr, const float m) {
+    if (tri_outside_cone(rec, tr, m, true)) return true;
+    const float4 hm = rec[8], s0 = rec[9], s1 = rec[10], h0 = rec[11], h1 = rec[12];
+    return plane_rules_out_box(s0.x, s0.y, s0.z, s1.x, s1.y, s1.z, h0.x, h0.y, h0.z, h1.x, h1.y, h1.z, hm.w, tr.nx, tr.ny, tr.nz, tr.nA);
+}
+
+// one leaf against the beam: true = some triangle may be hit (or a chunk that may never be culled is in the way)
+__device__ __forceinline__ bool beam_leaf(const uint32_t first, const uint32_t cnt, const uint32_t chunk0, const TriRec *__restrict__ tris,
+                                          const ChunkBound *__restrict__ chunks, const int lane, const float4 *shaft, const float4 *rec, const ShaftCtl &SC) {
+    const TriRec *__restrict__ T = tris + first;
+    const ChunkBound *__restrict__ cbounds = chunks + chunk0;
+    const uint32_t nchunk = (cnt + 63u) >> 6;
+    const int tk = lane & 7, tc = lane >> 3;
+    for (uint32_t cb0 = 0u; cb0 < nchunk; cb0 += 8u) {
+        const uint32_t myc = cb0 + static_cast<uint32_t>(tc);
+        const ChunkBound bd = cbounds[myc < nchunk ? myc : cb0];
+        const ShaftLanes SL = shaft_lanes_load(shaft, tk, SC);
+        bool near_out, far_out;
+        shaft_lane_test(SL, tk, bd.lo[0], bd.lo[1], bd.lo[2], bd.hi[0], bd.hi[1], bd.hi[2], near_out, far_out);
+        const unsigned long long b_out = __ballot(near_out && bd.never < 1.5f);
+        const uint32_t nhere = nchunk - cb0 < 8u ? nchunk - cb0 : 8u;
+        unsigned long long cm = __ballot(static_cast<uint32_t>(lane) < nhere && !ballot_byte_any(b_out, lane));      // bit j: chunk cb0 + j is in the beam
+        if (__ballot(static_cast<uint32_t>(lane) < nhere && ((cm >> lane) & 1ull) != 0ull && __shfl(bd.never, 8 * (lane & 7), 64) >= 1.5f) != 0ull) return true;
+        while (cm != 0ull) {
+            const int j = static_cast<int>(__builtin_ctzll(cm));
+            cm &= cm - 1ull;
+            const uint32_t c0 = (cb0 + static_cast<uint32_t>(j)) * 64u;
+            const uint32_t k = c0 + static_cast<uint32_t>(lane);
+            const TriRec tr = T[k < cnt ? k : 0u];
+            const bool hast = k < cnt && !(tr.flags & 1u);                        // (illum 9 faces never occlude: lightStrikes skips them)
+            if (__ballot(hast && !tri_outside_beam(rec, tr, lane_f(bd.infl, 8 * j) * 1.0625f)) != 0ull) return true;
+        }
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(RT_WAVES * 64) void k_beam(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris, const ChunkBound *__restrict__ chunks,
+                                                        const DScene S, const DLights L, const int level, const int lslots, const uint32_t item_cap,
+                                                        const ShadeItem *__restrict__ items, Control *__restrict__ ctl, unsigned long long *__restrict__ vis,
+                                                        uint32_t *__restrict__ sidx) {
+    __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
+    __shared__ float4 s_rec[RT_WAVES * RT_BEAM_REC];
+    __shared__ float4 s_shaft[RT_WAVES * 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *const stack = s_node + wave * RT_STACK;
+    float4 *const rec = s_rec + wave * RT_BEAM_REC;
+    float4 *const shaft = s_shaft + wave * 16;
+    const ShardMap imap = shard_map(ctl->n_items[level], lane, item_cap, 1u, 64u);        // tiles of 64 items, shard after shard
+    const uint32_t ntiles = imap.total;
+    if (ntiles == 0u) return;
+    const uint32_t N = static_cast<uint32_t>(L.n_samples);
+    const uint32_t P = (N + 63u) / 64u;
+    const bool blocks = sample_blocks(L);
+    const DNode root = nodes[0];
+    const int tk = lane & 7, tc = lane >> 3;
+    const float fi_last = static_cast<float>(L.usteps - 1) + 0.5f, fj_last = static_cast<float>(L.vsteps - 1) + 0.5f;
+    uint32_t c_rays = 0;
+    const uint32_t wave_id = uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave)), wave_count = gridDim.x * RT_WAVES;
+    for (uint32_t tile = wave_id; tile < ntiles; tile += wave_count) {
+        uint32_t sh, tj, n_sh;
+        shard_find(imap, tile, sh, tj, n_sh);
+        const bool have = tj * 64u + static_cast<uint32_t>(lane) < n_sh;
+        const uint32_t idx = sh * item_cap + tj * 64u + static_cast<uint32_t>(lane);     // item storage index (also keys vis)
+        const ShadeItem it = items[have ? idx : sh * item_cap];
+        const float hx = it.ox + it.t * it.dx, hy = it.oy + it.t * it.dy, hz = it.oz + it.t * it.dz;      // as the shadow kernels form it
+        const bool scene = have && it.lmode == 0u;              // sees the scene lights (a mirror bounce carries a light list of its own)
+        bool survive = have && !scene;
+        const unsigned long long sm0 = __ballot(scene);
+        if (sm0 != 0ull) {
+            // H: exact wave min / max of the hit points
+            float lx = scene ? hx : 3e38f, ly = scene ? hy : 3e38f, lz = scene ? hz : 3e38f;
+            float ux = scene ? hx : -3e38f, uy = scene ? hy : -3e38f, uz = scene ? hz : -3e38f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64)); lz = fminf(lz, __shfl_xor(lz, o, 64));
+                ux = fmaxf(ux, __shfl_xor(ux, o, 64)); uy = fmaxf(uy, __shfl_xor(uy, o, 64)); uz = fmaxf(uz, __shfl_xor(uz, o, 64));
+            }
+            const float cx = 0.5f * (lx + ux), cy = 0.5f * (ly + uy), cz = 0.5f * (lz + uz);
+            // half extent around the ROUNDED centre, rounded up
+            const float ex = fmaxf(ux - cx, cx - lx) * 1.0001f + 1e-7f * S.extent, ey = fmaxf(uy - cy, cy - ly) * 1.0001f + 1e-7f * S.extent,
+                        ez = fmaxf(uz - cz, cz - lz) * 1.0001f + 1e-7f * S.extent;
+            for (int l = 0; l < L.n_lights; ++l) {
+                float x0, y0, z0, x1, y1, z1;
+                const float px = L.pos[l][0], py = L.pos[l][1], pz = L.pos[l][2];
+                const LightGrid lg = light_grid(L, px, py, pz);
+                grid_sample(lg, 0.5f, 0.5f, x0, y0, z0);             // the samples are monotone in each grid index: two corners give the exact box
+                grid_sample(lg, fi_last, fj_last, x1, y1, z1);
+                if (L.mode == RT_LIGHT_SPHERE) sphere_box(L, px, py, pz, x0, y0, z0, x1, y1, z1);
+                const float slx = fminf(x0, x1), sly = fminf(y0, y1), slz = fminf(z0, z1), shx = fmaxf(x0, x1), shy = fmaxf(y0, y1), shz = fmaxf(z0, z1);
+                ShaftLanes SL = make_shaft_lanes(lane, cx, cy, cz, slx, sly, slz, shx, shy, shz, S.extent);
+                shaft_inflate(SL, tk, ex, ey, ez);
+                const ShaftCtl SC{SL.pad, false};
+                __builtin_amdgcn_wave_barrier();
+                shaft_tri_store(rec, lane, SL, cx, cy, cz, slx, sly, slz, shx, shy, shz);
+                shaft_lanes_store(shaft, lane, SL);
+                if (lane == 8) {
+                    const float m0 = 2e-5f * (((fabsf(slx) + fabsf(shx)) + (fabsf(sly) + fabsf(shy)) + (fabsf(slz) + fabsf(shz))) +
+                                              ((fabsf(lx) + fabsf(ux)) + (fabsf(ly) + fabsf(uy)) + (fabsf(lz) + fabsf(uz))));
+                    rec[8] = make_float4(cx, cy, cz, m0); rec[11] = make_float4(lx, ly, lz, 0.f); rec[12] = make_float4(ux, uy, uz, 0.f);
+                }
+                __builtin_amdgcn_wave_barrier();
+                // ---- the walk: groups of children by content box, leaves chunk by chunk, triangle by triangle
+                bool blocked = false;
+                int sp = 0;
+                if (root.count_flags & RT_NODE_LEAF) {
+                    blocked = (root.count_flags & 0x7fffffffu) != 0u &&
+                              beam_leaf(uniform_u32(root.first), uniform_u32(root.count_flags) & 0x7fffffffu, uniform_u32(root.pad[0]), tris, chunks, lane, shaft, rec, SC);
+                } else if ((root.count_flags & 0xfu) != 0u) {
+                    if (lane == 0) stack[0] = root.first | ((root.count_flags & 0xfu) << 28);
+                    sp = 1;
+                }
+                while (sp > 0 && !blocked) {
+                    --sp;
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t ent = uniform_u32(stack[sp]);
+                    const uint32_t base = ent & 0x0fffffffu, gcnt = ent >> 28;
+                    const DNode ch = nodes[base + (static_cast<uint32_t>(tc) < gcnt ? static_cast<uint32_t>(tc) : 0u)];
+                    const ShaftLanes SLg = shaft_lanes_load(shaft, tk, SC);
+                    bool c_near, c_far;
+                    shaft_lane_test(SLg, tk, ch.clo[0] - SC.pad, ch.clo[1] - SC.pad, ch.clo[2] - SC.pad, ch.chi[0] + SC.pad, ch.chi[1] + SC.pad, ch.chi[2] + SC.pad, c_near, c_far);
+                    const unsigned long long b_c = __ballot(c_near && ch.pad[1] == 0u);
+                    unsigned long long surv = __ballot(static_cast<uint32_t>(lane) < gcnt && !ballot_byte_any(b_c, lane));
+                    while (surv != 0ull && !blocked) {
+                        const int j = static_cast<int>(__builtin_ctzll(surv));
+                        surv &= surv - 1ull;
+                        const uint32_t cf = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.count_flags), 8 * j));
+                        const uint32_t ff = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.first), 8 * j));
+                        if (cf & RT_NODE_LEAF) {
+                            const uint32_t lc = cf & 0x7fffffffu;
+                            if (lc != 0u) blocked = beam_leaf(ff, lc, static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.pad[0]), 8 * j)), tris, chunks, lane, shaft, rec, SC);
+                        } else if ((cf & 0xfu) != 0u) {
+                            if (lane == 0) stack[sp] = ff | ((cf & 0xfu) << 28);
+                            ++sp;
+                        }
+                    }
+                }
+                RT_PROF_ADD(lane, 76, 1); RT_PROF_ADD(lane, 77, blocked ? 0 : 1);
+                if (blocked) {
+                    survive = survive || scene;
+                } else if (scene) {
+                    // nothing can block any sample segment of these hits to light l: all N samples visible
+                    const unsigned long long slot0 = (static_cast<unsigned long long>(idx) * static_cast<unsigned long long>(lslots) + static_cast<unsigned long long>(l)) * P;
+                    for (uint32_t p = 0u; p < P; ++p) {
+                        const uint32_t left = N - p * 64u;
+                        vis[slot0 + p] = (blocks || left >= 64u) ? ~0ull : ((1ull << left) - 1ull);
+                    }
+                }
+            }
+        }
+        // hits that need no shadow unit at all: their sample rays are accounted for here (the shadow kernels count the others)
+        c_rays += (have && !survive) ? N * static_cast<uint32_t>(L.n_lights) : 0u;
+        const unsigned long long sm = __ballot(survive);
+        if (sm != 0ull) {
+            bool fits;
+            const uint32_t at = shard_reserve(ctl->n_sitems[level], &ctl->overflow, tile, static_cast<uint32_t>(__popcll(sm)), item_cap, lane, fits);
+            if (survive && fits) sidx[at + lanes_below(sm)] = idx;
+        }
+    }
     c_rays = wave_sum(c_rays);
     if (lane == 0 && c_rays) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_SAMPLE], static_cast<unsigned long long>(c_rays));
 }
@@ -2767,9 +2992,10 @@ void launch_stage(bool primary, bool count, int stage, bool cont, int grid, hipS
     }
 }
 
-#define RT_LAUNCH_SHADOW(C, F, K) hipLaunchKernelGGL((k_shadow<C, F, K>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, L, level, slot, lslots, item_cap, items, ctl, vis, Q)
+#define RT_LAUNCH_SHADOW(C, F, K) hipLaunchKernelGGL((k_shadow<C, F, K>), g, b, 0, st, S.nodes, S.leaf_tris, S.chunks, S.leaf_chunk0, S, L, level, slot, lslots, item_cap, items, ctl, vis, Q, sidx)
 void launch_shadow(bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
-                   uint32_t item_cap, const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target) {
+                   uint32_t item_cap, const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target,
+                   const uint32_t *sidx) {
     const dim3 g(grid), b(RT_WAVES * 64);
     const TaskQueues Q{nullptr, (flat || count) ? nullptr : tasks_out, 0u, 2u, cap, (flat || count) ? 0u : budget, target};
     if (count) { if (flat) RT_LAUNCH_SHADOW(true, true, false); else RT_LAUNCH_SHADOW(true, false, false); }
@@ -2777,30 +3003,35 @@ void launch_shadow(bool count, bool flat, int grid, hipStream_t st, const DScene
 }
 
 void launch_shadow_shaft(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots, uint32_t item_cap,
-                         const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target) {
+                         const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target, const uint32_t *sidx) {
     const TaskQueues Q{nullptr, tasks_out, 0u, 2u, cap, budget, target};
     // (the task emission costs the walking kernel 30 more spilled registers: it is compiled in only when a budget asks for it)
     if (budget != 0u && tasks_out != nullptr)
-        hipLaunchKernelGGL((k_shadow_shaft<false, true>), dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S, L, level, slot, lslots, item_cap, items, ctl, vis, Q);
+        hipLaunchKernelGGL((k_shadow_shaft<false, true>), dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S, L, level, slot, lslots, item_cap, items, ctl, vis, Q, sidx);
     else
-        hipLaunchKernelGGL((k_shadow_shaft<false, false>), dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S, L, level, slot, lslots, item_cap, items, ctl, vis, Q);
+        hipLaunchKernelGGL((k_shadow_shaft<false, false>), dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S, L, level, slot, lslots, item_cap, items, ctl, vis, Q, sidx);
 }
 
 // the leaf tasks of a shaft-walk launch: chunk ranges of big leaves, through the same leaf code (shaft_leaf)
 void launch_shadow_shaft_cont(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, uint32_t item_cap, const ShadeItem *items,
-                              Control *ctl, unsigned long long *vis, const ContTask *tasks_in, uint32_t cap) {
+                              Control *ctl, unsigned long long *vis, const ContTask *tasks_in, uint32_t cap, const uint32_t *sidx) {
     const TaskQueues Q{tasks_in, nullptr, 2u, 0u, cap, 0u};
-    hipLaunchKernelGGL((k_shadow_shaft<true, false>), dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S, L, level, 0, lslots, item_cap, items, ctl, vis, Q);
+    hipLaunchKernelGGL((k_shadow_shaft<true, false>), dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S, L, level, 0, lslots, item_cap, items, ctl, vis, Q, sidx);
 }
 
 // processes the leaf tasks of queue q_in (leaf tasks never create new tasks)
 void launch_shadow_cont(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, uint32_t item_cap, const ShadeItem *items,
                         Control *ctl, unsigned long long *vis, const ContTask *tasks_in, ContTask *tasks_out, uint32_t q_in, uint32_t q_out,
-                        uint32_t cap, uint32_t budget) {
+                        uint32_t cap, uint32_t budget, const uint32_t *sidx) {
     const dim3 g(grid), b(RT_WAVES * 64);
     const int slot = 0;
     const TaskQueues Q{tasks_in, tasks_out, q_in, q_out, cap, tasks_out ? budget : 0u};
     RT_LAUNCH_SHADOW(false, false, true);
+}
+
+void launch_beam(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, uint32_t item_cap, const ShadeItem *items, Control *ctl,
+                 unsigned long long *vis, uint32_t *sidx) {
+    hipLaunchKernelGGL(k_beam, dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S, L, level, lslots, item_cap, items, ctl, vis, sidx);
 }
 
 void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level, int slot, int lslots,
