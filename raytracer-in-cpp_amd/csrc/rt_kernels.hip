@@ -1910,8 +1910,13 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(F
         // N > 64: the passes of one (hit, light) pair are consecutive units and walk the same part of the tree -- hand them out two
         // at a time (4K / 256 samples / 1 M triangles: k_shadow 40 -> 32 ms); otherwise balance first (neighbouring heavy units
         // pile up: dodge 1.03 -> 1.9 ms with chunks of 8)
-        q.init(ctl->queue[ctr_slot], static_cast<uint32_t>(units), gridDim.x * RT_WAVES, blockIdx.x, lane,
-               S.queue_local >= 0 ? static_cast<uint32_t>(S.queue_local) : (P > 1u ? 2u : 0u));
+        // (a launch with only a few units per wave -- what k_beam leaves of a flat scene -- would spend its time on the queue heads: one
+        // returning atomic per unit and 88 of them per microsecond and head; such a launch is dealt out statically)
+        if (FLAT && units < 16ull * gridDim.x * RT_WAVES)
+            q.init_static(static_cast<uint32_t>(units), gridDim.x * RT_WAVES, uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave)), lane);
+        else
+            q.init(ctl->queue[ctr_slot], static_cast<uint32_t>(units), gridDim.x * RT_WAVES, blockIdx.x, lane,
+                   S.queue_local >= 0 ? static_cast<uint32_t>(S.queue_local) : (P > 1u ? 2u : 0u));
     }
 #ifdef RT_PROFILE
     PhaseClock pclk; pclk.start();
