@@ -62,6 +62,9 @@ COST = {
     "unit_shaft": 270,           # k_shadow_shaft per unit: queue, item, sample, root test, shaft planes (make_shaft_lanes ~95), LDS records
     "unit_flat": 355,            # flat k_shadow per unit: queue, item, h, shaft planes (~85), 8 triangles x 8 tests per step (2 x ~45 on the cube), plane rule, visibility word
     "unit_stack": 200,
+    "beam": 700,                 # k_beam per (tile of 64 hits, light) on a flat scene: items, wave min / max, planes, one leaf (chunk test + per-triangle test)
+    "shade_sample": 187,         # k_shade per (tile of 64 hits, sample): light direction + reflection normalised (2 x sqrt + 6 IEEE divisions), glibc powf in double
+    "shade_tile": 500,           # k_shade per tile: items, interpolated normal, eye vector, material, record
 }
 
 
@@ -116,7 +119,7 @@ def valu_model(work, flat, shaft):
     w = work["shadow"]
     useful = w["tri_steps_lanes_triangles"] * COST["tri_lanes_triangles"] + w["tri_steps_lanes_rays"] * COST["tri_lanes_rays_shaft" if shaft and not flat else "tri_lanes_rays"]
     if flat:
-        return useful, useful + w["units"] * COST["unit_flat"]
+        return useful, useful + w["units"] * COST["unit_flat"] + w.get("beams_tested", 0) * COST["beam"]
     if shaft:
         useful += w["nodes_tested_per_ray"] * COST["node_per_ray"]
         total = useful + w["units"] * COST["unit_shaft"] + w["shaft_groups"] * COST["shaft_group"] + w["leaf_chunk_batches"] * COST["leaf_chunk_batch"] + \
@@ -241,8 +244,30 @@ def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, c
                                          "note": "SURVEY 8(d) algorithmic bytes (no early-out, no culling); a workload size, NOT a utilisation: above the HBM peak by construction"}
     roof["avg_launch_ms"] = round(avg_ms_shadow, 5)
     roof["launches_per_frame"] = launches_per_frame
+    roof["group"] = "shadow"
     roof["timing_source"] = f"HIP events on the launch stream inside the timed region (every 4th step: {K_t} of {steps} frames)"
-    roof["ms_per_frame"] = {"shadow": round(ms_shadow_frame, 4), "device_total": round(tim.ms_total / K_t, 4),
+    # ---- the shading kernel, same model: tiles of 64 hits x samples
+    ms_shade_frame = tim.ms_shade / K_t
+    tiles = (cnt.shaded_hits + 63) // 64
+    sh_useful = tiles * G * G * COST["shade_sample"]
+    sh_total = sh_useful + tiles * COST["shade_tile"]
+    t_ns = max(ms_shade_frame, 1e-6) * 1e6
+    shade = {"bound": "valu", "group": "shade", "kernel": "k_shade (phongShade over the samples: two normalisations and one libm-exact powf per sample)",
+             "unit": "wave-instructions/SIMD/ns", "peak": VALU_PEAK_PER_SIMD_NS, "peak_source": roof["peak_source"],
+             "achieved": round(sh_total / t_ns / N_SIMDS, 4), "frac": round(sh_total / t_ns / N_SIMDS / VALU_PEAK_PER_SIMD_NS, 4),
+             "useful_frac": round(sh_useful / t_ns / N_SIMDS / VALU_PEAK_PER_SIMD_NS, 4),
+             "modelled_valu_wave_instructions_per_frame": {"useful": int(sh_useful), "total": int(sh_total)},
+             "work": {"shade": {"tiles_of_64_hits": int(tiles), "samples": G * G}}, "cost_per_step": COST,
+             "traffic": None, "hbm_frac": None, "timing_source": roof["timing_source"] if "timing_source" in roof else ""}
+    ent, why = pmc_constant("valu.json", scene, cfg, sha)
+    if ent and "rtamd::k_shade" in ent["kernels"]:
+        insts = ent["kernels"]["rtamd::k_shade"]["valu_wave_instructions"]
+        r = insts / t_ns / N_SIMDS
+        shade["executed_valu"] = {"constant": True, "wave_instructions_per_frame_level0": int(insts), "per_simd_per_ns": round(r, 4),
+                                  "frac": round(r / VALU_PEAK_PER_SIMD_NS, 4), "source": ent["how"]}
+    else:
+        shade["executed_valu"] = {"constant": True, "frac": None, "why": why or "no k_shade entry"}
+    roof["ms_per_frame"] = {"shadow": round(ms_shadow_frame, 4), "shade": round(ms_shade_frame, 4), "device_total": round(tim.ms_total / K_t, 4),
                             "instrumented_frame": {"trace": round(brk.ms_trace, 4), "shadow": round(brk.ms_shadow, 4), "shade": round(brk.ms_shade, 4),
                                                    "resolve": round(brk.ms_resolve, 4), "total": round(brk.ms_total, 4)}}
 
@@ -252,6 +277,13 @@ def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, c
                       "tree": {k: info[k] for k in ("nodes", "leaves", "face_refs", "max_leaf", "depth")}},
            "rays": {"primary": cnt.rays_primary, "centre": cnt.rays_centre, "sample": cnt.rays_sample, "bounce": cnt.rays_bounce, "culled_pixels": cnt.pixels_culled},
            "roofline": roof}
+    shade["ms_per_frame"] = roof["ms_per_frame"]
+    shade["timing_source"] = roof["timing_source"]
+    # `roofline` is the group that takes most of the frame; the other one stays beside it
+    if ms_shade_frame > ms_shadow_frame:
+        rec["roofline"], rec["roofline_shadow"] = shade, roof
+    else:
+        rec["roofline_shade"] = shade
 
     if want_graph:
         # extra (untimed for `value`): K frames replayed from ONE captured hipGraph, camera yaw stepping 2*pi/120 per frame (BASELINE cfg5)

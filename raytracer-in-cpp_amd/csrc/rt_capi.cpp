@@ -685,7 +685,7 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));   // after the whole shadow group (incl. continuations)
         launch_set_prof(st, c->d_ctl, 0u);
         launch_shade(c->cus * c->occ_shade, st, c->S, L, F, level, 3 * level + 2, lslots, c->d_items, c->d_ctl, c->d_vis, rec_l, fres_l, c->d_rays[(level + 1) & 1]);
-        if (timed == 1) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
+        if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));        // after k_shade (lean timing too: the shade interval is a single kernel)
     }
     DFrame Fr = F;
     Fr.max_depth = levels_run - 1;
@@ -700,9 +700,10 @@ static rt_status sum_frame_times(rt_ctx *c, size_t ev, int levels_run, rt_stats 
     const size_t first = ev;
     for (int level = 0; level < levels_run; ++level) {
         if (lean) {
-            // events: [.. trace ..] E [shadow] E [.. shade, next trace ..]: only the shadow interval is a single kernel
+            // events: [.. trace ..] E [beam, shadow] E [shade] E [.. next trace ..]
             ++ev;
             HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_shadow += ms; ++ev;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_shade += ms; ++ev;
         } else {
             HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_trace += ms; ++ev;
             HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_shadow += ms; ++ev;
@@ -847,7 +848,7 @@ extern "C" rt_status rt_render_device(rt_ctx *c, const rt_camera *cam, const rt_
         const size_t first = c->ev_base;
         if ((s = run_frame(c, st, &dc, L, F, true, false, d_out_rgb, d_out_u8, d_out_hit, nullptr, 2, 0)) != RT_OK) return s;
         c->pending.emplace_back(first, levels_run);
-        c->ev_base = first + static_cast<size_t>(2 * levels_run + 2);
+        c->ev_base = first + static_cast<size_t>(3 * levels_run + 2);
         c->pending_stream = st;
         c->pending_frame = F;
         return RT_OK;

@@ -32,27 +32,45 @@ def test_headline_has_the_contract_fields():
     assert DEFAULT["tree_scenes"]["cfg4_wavy_3840x2160_d8_s256"]["config"]["tree"]["nodes"] > 1000
 
 
+def rooflines(d):
+    """`roofline` is the kernel group that takes most of the frame (shadow group or k_shade); the other one is kept beside it"""
+    out = [d["roofline"]]
+    for k in ("roofline_shadow", "roofline_shade"):
+        if k in d:
+            out.append(d[k])
+    return out
+
+
 @pytest.mark.parametrize("name,d", records())
 def test_every_record_is_consistent_and_its_roofline_physical(name, d):
     # value = rays of the frame / time of a step
     assert abs(d["value"] - d["rays_per_frame"] / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-3 * d["value"]
-    r = d["roofline"]
-    assert r["bound"] == "valu" and r["unit"] == "wave-instructions/SIMD/ns" and r["peak"] == 0.967
-    # PHYSICAL: 0 < frac <= 1, frac = achieved / peak, and re-derivable from the line itself: modelled instructions / launch time
-    assert 0.0 < r["useful_frac"] <= r["frac"] <= 1.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 2e-3
-    total = r["modelled_valu_wave_instructions_per_frame"]["total"]
-    assert abs(r["achieved"] - total / (r["ms_per_frame"]["shadow"] * 1e6) / 1024) <= 2e-3 * max(1.0, r["achieved"])
-    # the model is steps x cost, both in the line
-    w, c = r["work"]["shadow"], r["cost_per_step"]
-    assert w["units"] > 0 and (w["tri_steps_lanes_triangles"] + w["tri_steps_lanes_rays"]) > 0
-    assert total >= w["tri_steps_lanes_triangles"] * c["tri_lanes_triangles"] + w["tri_steps_lanes_rays"] * c["tri_lanes_rays"]
-    # PMC constants: quoted (then physical too) or explicitly null
-    ev = r["executed_valu"]
-    assert ev["constant"] is True and (ev["frac"] is None or r["frac"] * 0.5 <= ev["frac"] <= 1.0)
-    assert r["traffic"] is None or (r["traffic"] > 0 and 0.0 < r["hbm_frac"] <= 1.0)
-    assert r["reference_semantics_bytes"]["per_frame_k_shadow"] > 0
-    assert "HIP events" in r["timing_source"]
+    groups = {r["group"] for r in rooflines(d)}
+    assert groups == {"shadow", "shade"}
+    ms = d["roofline"]["ms_per_frame"]
+    assert d["roofline"]["group"] == ("shade" if ms["shade"] > ms["shadow"] else "shadow")       # the dominant group carries the name `roofline`
+    for r in rooflines(d):
+        assert r["bound"] == "valu" and r["unit"] == "wave-instructions/SIMD/ns" and r["peak"] == 0.967
+        # PHYSICAL: 0 < frac <= 1, frac = achieved / peak, and re-derivable from the line itself: modelled instructions / group time
+        assert 0.0 <= r["useful_frac"] <= r["frac"] <= 1.0 and r["frac"] > 0.0
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 2e-3
+        total = r["modelled_valu_wave_instructions_per_frame"]["total"]
+        assert abs(r["achieved"] - total / (r["ms_per_frame"][r["group"]] * 1e6) / 1024) <= 2e-3 * max(1.0, r["achieved"])
+        c = r["cost_per_step"]
+        if r["group"] == "shadow":
+            # the model is steps x cost, both in the line
+            w = r["work"]["shadow"]
+            assert w["units"] > 0
+            assert total >= w["tri_steps_lanes_triangles"] * c["tri_lanes_triangles"] + w["tri_steps_lanes_rays"] * c["tri_lanes_rays"]
+            assert r["reference_semantics_bytes"]["per_frame_k_shadow"] > 0
+        else:
+            w = r["work"]["shade"]
+            assert total == w["tiles_of_64_hits"] * (w["samples"] * c["shade_sample"] + c["shade_tile"])
+        # PMC constants: quoted (then physical too) or explicitly null
+        ev = r["executed_valu"]
+        assert ev["constant"] is True and (ev["frac"] is None or r["frac"] * 0.5 <= ev["frac"] <= 1.0)
+        assert r["traffic"] is None or (r["traffic"] > 0 and 0.0 < r["hbm_frac"] <= 1.0)
+        assert "HIP events" in r["timing_source"]
     c = d["cpu_baseline"]
     assert c["unit"] == "Mrays/s" and c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
 
@@ -60,15 +78,19 @@ def test_every_record_is_consistent_and_its_roofline_physical(name, d):
 @pytest.mark.parametrize("scene,kernel", [("cube", "k_shadow<false, true, false>"), ("dodge", "k_shadow_shaft"), ("wavy", "k_shadow_shaft")])
 def test_rocprof_kernel_stats_agree_with_the_event_times(scene, kernel):
     """profiles/r02_<scene>_kernel_stats.csv (rocprofv3 --kernel-trace --stats over bench.py) against the HIP-event time of the SAME run
-    (profiles/r02_bench_<scene>_under_rocprof.json): the shadow group's average duration per frame agrees within 10 %."""
+    (profiles/r02_bench_<scene>_under_rocprof.json): the shadow group's average duration per frame agrees within 10 % (+ 4 us per launch of the
+    group for the gaps the event interval contains)."""
     rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"r02_{scene}_kernel_stats.csv"))))
-    shadow = [r for r in rows if "k_shadow" in r["Name"] and "<true" not in r["Name"]]
+    shadow = [r for r in rows if ("k_shadow" in r["Name"] or "k_beam" in r["Name"]) and "<true" not in r["Name"]]      # the shadow GROUP: beam test + shadow units
     assert any(kernel in r["Name"] for r in shadow)
     bench = json.load(open(os.path.join(ROOT, "profiles", f"r02_bench_{scene}_under_rocprof.json")))
-    frames = max(int(r["Calls"]) for r in shadow) / bench["roofline"]["launches_per_frame"]
+    rs = bench["roofline"] if bench["roofline"]["group"] == "shadow" else bench["roofline_shadow"]
+    frames = max(int(r["Calls"]) for r in shadow if "k_shadow" in r["Name"]) / rs["launches_per_frame"]
     ms_rocprof = sum(float(r["TotalDurationNs"]) for r in shadow) / frames / 1e6
-    ms_events = bench["roofline"]["ms_per_frame"]["shadow"]
-    assert abs(ms_rocprof - ms_events) <= 0.10 * ms_events, (ms_rocprof, ms_events)
+    ms_events = rs["ms_per_frame"]["shadow"]
+    # the event interval of a group also holds the gaps between its launches (the cube's group is ten launches of a few microseconds each)
+    launches = sum(int(r["Calls"]) for r in shadow) / frames
+    assert -0.10 * ms_events <= ms_events - ms_rocprof <= 0.10 * ms_events + launches * 0.004, (ms_rocprof, ms_events, launches)
 
 
 def test_pmc_constants_are_stamped_with_the_kernels_source():
