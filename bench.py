@@ -110,7 +110,7 @@ def work_counters(pkg, hs, W, H, G, D):
     t = a[0:96]
     names = {0: "tri_steps_lanes_rays", 2: "tri_steps_lanes_triangles", 4: "box_steps_stack_walk", 12: "chunk_tests_stack_walk", 13: "units",
              88: "shaft_groups", 90: "nodes_tested_per_ray", 91: "nodes_hit", 92: "leaf_chunk_batches", 94: "chunks_tested_per_ray", 95: "chunks_with_work",
-             70: "tri_shaft_tests", 71: "tri_shaft_survivors", 72: "tri_shaft_rays", 73: "tri_shaft_empty_chunks", 74: "node_test_live_rays", 75: "node_hit_rays", 76: "beams_tested", 77: "beams_unblocked"}
+             70: "tri_shaft_tests", 71: "tri_shaft_survivors", 72: "tri_shaft_rays", 73: "tri_shaft_empty_chunks", 74: "node_test_live_rays", 75: "node_hit_rays", 76: "beams_tested", 77: "beams_unblocked", 78: "beam_hits_checked_per_leaf_list", 79: "beam_hits_that_reach_a_bad_leaf", 80: "beam_steps_of_unblocked", 81: "beams_over_budget"}
     return {"shadow": {v: s[k] for k, v in names.items()}, "trace": {v: t[k] for k, v in names.items()}}
 
 

@@ -59,7 +59,7 @@ struct rt_ctx {
     // scene
     bool has_scene = false;
     DScene S{};
-    void *d_chunks = nullptr, *d_leaf_chunk0 = nullptr;
+    void *d_chunks = nullptr, *d_leaf_chunk0 = nullptr, *d_bad_leaves = nullptr;
     void *d_nodes = nullptr, *d_tris = nullptr, *d_tri_verts = nullptr, *d_face_normal = nullptr, *d_tri_vid = nullptr,
          *d_mat_id = nullptr, *d_vert_normal = nullptr, *d_mats = nullptr;
     bool reflective = false;     // some material spawns bounce rays (illum 3,4,5,6,9)
@@ -171,7 +171,7 @@ extern "C" rt_status rt_create(rt_ctx **out, int device) {
 }
 
 static void free_scene(rt_ctx *c) {
-    void **p[] = {&c->d_chunks, &c->d_leaf_chunk0, &c->d_nodes, &c->d_tris, &c->d_tri_verts, &c->d_face_normal, &c->d_tri_vid, &c->d_mat_id, &c->d_vert_normal, &c->d_mats};
+    void **p[] = {&c->d_bad_leaves, &c->d_chunks, &c->d_leaf_chunk0, &c->d_nodes, &c->d_tris, &c->d_tri_verts, &c->d_face_normal, &c->d_tri_vid, &c->d_mat_id, &c->d_vert_normal, &c->d_mats};
     for (void **q : p) { if (*q) (void)hipFree(*q); *q = nullptr; }
     c->has_scene = false;
 }
@@ -255,6 +255,24 @@ static uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {
     return spread(x) | (spread(y) << 1) | (spread(z) << 2);
 }
 
+// A triangle that rayTriangleIntersection (flyscene.cpp:787-819) can never accept, whatever the ray: a zero face normal gives
+// dn = d.n = 0 for every finite direction (`dn == 0` -> rejected); a NaN normal makes t, u, v NaN (every comparison false); and when the
+// float denominator d00*d11 - d01*d01 -- evaluated as the reference evaluates it -- is 0 or NaN, 1/denom is inf / NaN and u, v are each
+// +-inf or NaN: u >= 0 && v >= 0 && u + v < 1 cannot hold.  Collinear triangles of real meshes are mostly of this kind; the others (a
+// denominator that is one rounding error instead of zero) report hits wherever their plane is crossed and stay un-cullable.
+static bool never_hit(const float *v, const float *nn) {
+    if (!(nn[0] == nn[0]) || !(nn[1] == nn[1]) || !(nn[2] == nn[2])) return true;
+    if (nn[0] == 0.0f && nn[1] == 0.0f && nn[2] == 0.0f) {
+        for (int k = 0; k < 9; ++k) if (!std::isfinite(v[k])) return false;
+        return true;
+    }
+    const V3 A{v[0], v[1], v[2]}, B{v[3], v[4], v[5]}, C{v[6], v[7], v[8]};
+    const V3 e0 = C - A, e1 = B - A;
+    const float d00 = dot(e0, e0), d01 = dot(e0, e1), d11 = dot(e1, e1);
+    const float inv = 1 / (d00 * d11 - d01 * d01);
+    return !std::isfinite(inv);
+}
+
 static void build_chunk_bounds(const rt_scene *sc, std::vector<uint32_t> &refs, std::vector<uint32_t> &leaf_chunk0,
                                std::vector<ChunkBound> &out, float extent, bool no_cull) {
     for (uint32_t ni = 0; ni < sc->n_nodes; ++ni) {
@@ -287,10 +305,13 @@ static void build_chunk_bounds(const rt_scene *sc, std::vector<uint32_t> &refs, 
             ChunkBound cb{};
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, max_edge = 0, bary_infl = 0;
             bool ok = !no_cull;
+            uint32_t live_tris = 0;
             for (uint32_t i = 0; i < n && ok; ++i) {
                 const uint32_t f = r[c0 + i];
                 const float *v = sc->tri_verts + static_cast<size_t>(f) * 9;
                 const float *nn = sc->face_normal + static_cast<size_t>(f) * 3;
+                if (never_hit(v, nn)) continue;         // cannot be hit by any ray AS THE REFERENCE COMPUTES IT: no bound needed for it
+                ++live_tris;
                 for (int k = 0; k < 9; ++k) if (!std::isfinite(v[k])) ok = false;
                 const double nl = std::sqrt(double(nn[0]) * nn[0] + double(nn[1]) * nn[1] + double(nn[2]) * nn[2]);
                 if (!std::isfinite(nl) || std::fabs(nl - 1.0) > 1e-3) { ok = false; break; }   // Face::normal is unit unless degenerate
@@ -319,6 +340,7 @@ static void build_chunk_bounds(const rt_scene *sc, std::vector<uint32_t> &refs, 
                 cb.never = 0.0f;
                 cb.infl = std::nextafter(static_cast<float>(infl), INFINITY);
             }
+            if (ok && live_tris == 0) { for (int k = 0; k < 3; ++k) cb.lo[k] = cb.hi[k] = 1e30f; cb.infl = 0.0f; }     // nothing hittable inside: a far-away point
             if (!ok) { cb = ChunkBound{}; cb.never = 2.0f; }
             out.push_back(cb);
         }
@@ -419,6 +441,7 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     rt_status st;
     // device nodes = public nodes + content boxes, bottom-up (children always follow their parent in the array)
     std::vector<DNode> dnodes(sc->n_nodes);
+    std::vector<float> bad_leaves;            // boxes of the leaves with a chunk that may never be culled (k_beam)
     for (uint32_t ii = sc->n_nodes; ii-- > 0;) {
         const rt_node &n = sc->nodes[ii];
         DNode &dn = dnodes[ii];
@@ -438,6 +461,7 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
                 const ChunkBound &cb = cbs[leaf_chunk0[ii] + k];
                 if (cb.never >= 1.5f) open_box = true; else grow(cb.lo, cb.hi);
             }
+            if (open_box) { for (int k = 0; k < 3; ++k) bad_leaves.push_back(n.bmin[k]); for (int k = 0; k < 3; ++k) bad_leaves.push_back(n.bmax[k]); }
         } else {
             for (uint32_t k = 0; k < cnt; ++k) {
                 const DNode &ch = dnodes[n.first + k];
@@ -463,6 +487,9 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     if ((st = upload(c, &c->d_tris, recs.data(), recs.size())) != RT_OK) return st;
     if ((st = upload(c, &c->d_chunks, cbs.data(), cbs.size())) != RT_OK) return st;
     if ((st = upload(c, &c->d_leaf_chunk0, leaf_chunk0.data(), leaf_chunk0.size())) != RT_OK) return st;
+    const size_t n_bad = bad_leaves.size() / 6;
+    if (bad_leaves.empty()) bad_leaves.assign(6, 0.0f);
+    if ((st = upload(c, &c->d_bad_leaves, bad_leaves.data(), bad_leaves.size())) != RT_OK) return st;
     if ((st = upload(c, &c->d_tri_verts, sc->tri_verts, static_cast<size_t>(sc->n_faces) * 9)) != RT_OK) return st;
     if ((st = upload(c, &c->d_face_normal, sc->face_normal, static_cast<size_t>(sc->n_faces) * 3)) != RT_OK) return st;
     if ((st = upload(c, &c->d_tri_vid, sc->tri_vid, static_cast<size_t>(sc->n_faces) * 3)) != RT_OK) return st;
@@ -473,6 +500,8 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     c->S.leaf_tris = static_cast<const TriRec *>(c->d_tris);
     c->S.chunks = static_cast<const ChunkBound *>(c->d_chunks);
     c->S.leaf_chunk0 = static_cast<const uint32_t *>(c->d_leaf_chunk0);
+    c->S.bad_leaves = static_cast<const float *>(c->d_bad_leaves);
+    c->S.n_bad_leaves = n_bad <= 32 ? static_cast<uint32_t>(n_bad) : 0xffffffffu;
     c->S.extent = extent;
     c->S.tri_verts = static_cast<const float *>(c->d_tri_verts);
     c->S.face_normal = static_cast<const float *>(c->d_face_normal);
@@ -663,9 +692,10 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
         launch_set_prof(st, c->d_ctl, RT_WORK_SHADOW);
         // one (hit, light) pair per wave (N > 32 samples): first the beam test of whole tiles of 64 hits (k_beam: the hits whose sample rays
         // nothing can block get their visibility words there and never become shadow units), then the survivors
-        // (tree scenes: off unless RT_BEAM_TREES=1 -- a beam has to walk everything it touches before it may say "unblocked", one wave per
-        // beam; measured: dodge 85 % of the tiles unblockable but for its 15 degenerate triangles, whose computed barycentrics are noise --
-        // no bound on where they report a hit; cfg4 9 % unblocked and +4.7 ms for finding that out)
+        // (tree scenes: off unless RT_BEAM_TREES=1.  Measured on dodgeColorTest.obj 1080p/64: 84 % of the 3,332 tiles come out unblocked -- none
+        // of their hits can reach a leaf with one of the model's degenerate triangles -- and the shadow units drop from 213k to 33k, but a beam
+        // walks ~370 steps alone in its wave (k_beam 0.30 ms) and the units that remain are the expensive ones (penumbra, cluttered parts:
+        // 0.60 ms of the former 0.77): 0.90 ms against 0.77.  cfg4: 9 % unblocked; the launch's own brake stops testing after 4k of 18k tiles.)
         const bool beam = !count && c->S.beam != 0 && L.n_samples > 32 && (c->flat || c->beam_trees);
         const uint32_t *sidx = beam ? c->d_sidx : nullptr;
         if (beam) launch_beam(c->cus * 4, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_sidx);

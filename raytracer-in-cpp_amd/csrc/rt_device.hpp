@@ -128,6 +128,8 @@ struct DScene {
     int32_t queue_local;               // k_shadow queue: -1 auto, 0 strided chunks (balance first), n chunks of n consecutive units
     int32_t plane_cull;                // k_shadow: per-unit plane culling (rt_kernels.hip, SegPacket); RT_NO_PLANE_CULL=1 turns it off
     int32_t queue_div;                 // k_shadow_shaft: units are handed out in chunks of units / (waves x queue_div)
+    const float *bad_leaves;           // boxes (min, max) of the leaves that hold a chunk which may never be culled (k_beam tests them per hit)
+    uint32_t n_bad_leaves;             // 0xffffffff: too many for the per-hit test -- such a chunk then blocks every beam that meets it
     int32_t beam;                      // k_beam before the shadow kernels: whole tiles of 64 lit hits whose sample rays nothing can block; RT_NO_BEAM=1 turns it off
     int32_t shaft;                     // k_shadow on tree scenes: shaft-culled group walk (rt_kernels.hip, shaft_walk); RT_NO_SHAFT=1 turns it off
 };
@@ -183,7 +185,8 @@ struct Control {
     // leaf tasks of the shadow kernels: RT_LIST_SHARDS sub-queues (producer block % RT_LIST_SHARDS), each counter on its own line --
     // one returning atomic per emitting leaf visit on a SINGLE word (~60k per dodge launch) ran into the ~88 per us limit
     uint32_t n_task_sh[RT_MAX_DEPTH + 1][RT_LIST_SHARDS * 16];
-    uint32_t n_sitems[RT_MAX_DEPTH + 1][RT_LIST_SHARDS * 16];  // lit hits per level and shard that still need their sample shadow rays (k_beam's survivors)
+    uint32_t n_sitems[RT_MAX_DEPTH + 1][RT_LIST_SHARDS * 16];
+    uint32_t beam_yield[RT_MAX_DEPTH + 1][RT_LIST_SHARDS * 16]; // k_beam's own brake: shard s (a line of its own) holds beams tested [16 s] / unblocked [16 s + 1] so far  // lit hits per level and shard that still need their sample shadow rays (k_beam's survivors)
     // totals, filled on the HOST by fold_stats() from the sharded counters below
     unsigned long long rays_primary, rays_bounce, rays_centre, rays_sample, pixels_culled, shaded_hits;
     unsigned long long box_tests, leaf_tri_refs;              // k_trace (closest hit + light-centre rays)

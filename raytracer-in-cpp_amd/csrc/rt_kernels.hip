@@ -2374,6 +2374,50 @@ __device__ __forceinline__ void shaft_inflate(ShaftLanes &SL, const int tk, cons
         SL.r[0] -= ex; SL.r[1] -= ey; SL.r[2] -= ez; SL.r[3] += ex; SL.r[4] += ey; SL.r[5] += ez;
     }
 }
+// ---- lane-local shaft of ONE hit: every lane builds the six tangent planes of its own (S, h) -- the construction of make_shaft_lanes with
+// the projection and the tangent as compile-time constants -- and tests wave-uniform boxes against them.  Used by k_beam for the few
+// leaves that hold a chunk which may never be culled: can a ray from the light's samples to this hit, or its continuation behind the hit
+// (boxIntersect has no upper bound), enter the leaf's own box?  If not, the reference never looks at that leaf for this hit.
+struct ItemPlane { float a, b, c, far_margin; };     // a*u + b*v + c over the projection (u, v); unusable: never separates
+template <int PROJ, bool Q1>
+__device__ __forceinline__ ItemPlane item_plane(const float hx, const float hy, const float hz, const float slx, const float sly, const float slz,
+                                                const float shx, const float shy, const float shz, const float scale) {
+    const float hu = PROJ == 1 ? hy : hx, hv = PROJ == 2 ? hy : hz;
+    const float u0 = PROJ == 1 ? sly : slx, u1 = PROJ == 1 ? shy : shx;
+    const float v0 = PROJ == 2 ? sly : slz, v1 = PROJ == 2 ? shy : shz;
+    const bool ul = hu < u0, ur = hu > u1, vl = hv < v0, vr = hv > v1;
+    const bool su0 = !(ul || ur), sv0 = !(vl || vr);
+    const float near_u = ul ? u0 : u1, far_u = ul ? u1 : u0, near_v = vl ? v0 : v1, far_v = vl ? v1 : v0;
+    const float cu = Q1 ? (su0 ? u1 : (sv0 ? near_u : far_u)) : (su0 ? u0 : near_u);
+    const float cv = Q1 ? (sv0 ? v1 : near_v) : (sv0 ? v0 : (su0 ? near_v : far_v));
+    const float mu = 0.5f * (u0 + u1) - hu, mv = 0.5f * (v0 + v1) - hv;
+    const float nu = -(cv - hv), nv = cu - hu;
+    const float fm = nu * mu + nv * mv;
+    const float mag = fabsf(nu) + fabsf(nv);
+    const bool ok = !(su0 && sv0) && (fabsf(fm) > 1e-5f * mag * scale);
+    const float sgn = fm > 0.0f ? -1.0f : 1.0f;
+    const float margin = 2e-5f * mag * scale;
+    ItemPlane p;
+    p.a = ok ? sgn * nu : 0.0f; p.b = ok ? sgn * nv : 0.0f;
+    p.c = ok ? -(p.a * hu + p.b * hv) - margin : -1.0f;
+    p.far_margin = ok ? 2.0f * margin : 3e38f;
+    return p;
+}
+// box [lo, hi] (already padded) against one plane: near = outside the shaft by this plane, far = outside the far cone by it
+template <int PROJ>
+__device__ __forceinline__ void item_plane_test(const ItemPlane &p, const float lx, const float ly, const float lz, const float hx, const float hy, const float hz,
+                                                bool &near_out, bool &far_out) {
+    const float ul = PROJ == 1 ? ly : lx, uh = PROJ == 1 ? hy : hx, vl = PROJ == 2 ? ly : lz, vh = PROJ == 2 ? hy : hz;
+    const float ap = fmaxf(p.a, 0.0f), an = fminf(p.a, 0.0f), bp = fmaxf(p.b, 0.0f), bn = fminf(p.b, 0.0f);
+    const float mn = __builtin_fmaf(ap, ul, __builtin_fmaf(an, uh, __builtin_fmaf(bp, vl, __builtin_fmaf(bn, vh, p.c))));
+    const float mx = __builtin_fmaf(ap, uh, __builtin_fmaf(an, ul, __builtin_fmaf(bp, vh, __builtin_fmaf(bn, vl, p.c))));
+    near_out = near_out || (mn > 0.0f);
+    far_out = far_out || (mx + p.far_margin < 0.0f);
+}
+
+#ifndef RT_BEAM_BUDGET
+#define RT_BEAM_BUDGET 1024               // group steps + chunk bound batches + chunks tested triangle by triangle, per beam
+#endif
 #define RT_BEAM_REC 13                 // float4 per wave: shaft_tri_store's 11 (planes, near box, (h_c, m0), S lo, S hi) + H lo, H hi
 
 // lane = triangle: can ANY segment of the beam hit this triangle with a counted t?  (planes and near box from the relaxed record)
@@ -2385,7 +2429,8 @@ __device__ __forceinline__ bool tri_outside_beam(const float4 *rec, const TriRec
 
 // one leaf against the beam: true = some triangle may be hit (or a chunk that may never be culled is in the way)
 __device__ __forceinline__ bool beam_leaf(const uint32_t first, const uint32_t cnt, const uint32_t chunk0, const TriRec *__restrict__ tris,
-                                          const ChunkBound *__restrict__ chunks, const int lane, const float4 *shaft, const float4 *rec, const ShaftCtl &SC) {
+                                          const ChunkBound *__restrict__ chunks, const int lane, const float4 *shaft, const float4 *rec, const ShaftCtl &SC,
+                                          const bool per_item, int &budget) {
     const TriRec *__restrict__ T = tris + first;
     const ChunkBound *__restrict__ cbounds = chunks + chunk0;
     const uint32_t nchunk = (cnt + 63u) >> 6;
@@ -2399,7 +2444,12 @@ __device__ __forceinline__ bool beam_leaf(const uint32_t first, const uint32_t c
         const unsigned long long b_out = __ballot(near_out && bd.never < 1.5f);
         const uint32_t nhere = nchunk - cb0 < 8u ? nchunk - cb0 : 8u;
         unsigned long long cm = __ballot(static_cast<uint32_t>(lane) < nhere && !ballot_byte_any(b_out, lane));      // bit j: chunk cb0 + j is in the beam
-        if (__ballot(static_cast<uint32_t>(lane) < nhere && ((cm >> lane) & 1ull) != 0ull && __shfl(bd.never, 8 * (lane & 7), 64) >= 1.5f) != 0ull) return true;
+        // a chunk that may never be culled: its leaf is tested per hit afterwards (S.bad_leaves) -- or, without that list, it blocks the beam
+        const unsigned long long nv = __ballot(static_cast<uint32_t>(lane) < nhere && ((cm >> lane) & 1ull) != 0ull && __shfl(bd.never, 8 * (lane & 7), 64) >= 1.5f);
+        if (nv != 0ull && !per_item) return true;
+        cm &= ~nv;
+        budget -= 1 + static_cast<int>(__popcll(cm));
+        if (budget < 0) return true;                                       // too much work for one wave: let the shadow units decide
         while (cm != 0ull) {
             const int j = static_cast<int>(__builtin_ctzll(cm));
             cm &= cm - 1ull;
@@ -2433,8 +2483,16 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_beam(const DNode *__restrict_
     const DNode root = nodes[0];
     const int tk = lane & 7, tc = lane >> 3;
     const float fi_last = static_cast<float>(L.usteps - 1) + 0.5f, fj_last = static_cast<float>(L.vsteps - 1) + 0.5f;
+    const bool per_item = S.n_bad_leaves != 0xffffffffu;
+    const bool brake = (root.count_flags & RT_NODE_LEAF) == 0u;      // (a flat scene is one leaf: always cheap to test, nothing to watch)
     uint32_t c_rays = 0;
     const uint32_t wave_id = uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave)), wave_count = gridDim.x * RT_WAVES;
+    // The test only pays where most beams come out unblocked (a convex object, a car body under a light: 85-95 %); under grazing light over
+    // a height field 9 in 10 beams meet a triangle, after a long walk.  The launch watches its own yield: every wave reports (tested,
+    // unblocked) after each beam into one of 16 counter pairs, and once a pair holds 16 beams with fewer than a quarter unblocked the waves
+    // that report to it pass their remaining tiles on untested.  The results do not depend on it -- an untested tile simply goes to the shadow kernels.
+    uint32_t *const yield = ctl->beam_yield[level] + (blockIdx.x & (RT_LIST_SHARDS - 1u)) * 16u;      // this workgroup's shard (one returning or
+                                                                                                      // non-returning atomic word takes ~88 updates per microsecond)
     for (uint32_t tile = wave_id; tile < ntiles; tile += wave_count) {
         uint32_t sh, tj, n_sh;
         shard_find(imap, tile, sh, tj, n_sh);
@@ -2445,7 +2503,14 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_beam(const DNode *__restrict_
         const bool scene = have && it.lmode == 0u;              // sees the scene lights (a mirror bounce carries a light list of its own)
         bool survive = have && !scene;
         const unsigned long long sm0 = __ballot(scene);
-        if (sm0 != 0ull) {
+        bool give_up = false;
+        if (brake) {
+            const uint32_t y_t = uniform_u32(__hip_atomic_load(&yield[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const uint32_t y_u = uniform_u32(__hip_atomic_load(&yield[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            give_up = y_t >= 16u && y_u * 4u < y_t;
+        }
+        if (give_up) survive = have;
+        if (sm0 != 0ull && !give_up) {
             // H: exact wave min / max of the hit points
             float lx = scene ? hx : 3e38f, ly = scene ? hy : 3e38f, lz = scene ? hz : 3e38f;
             float ux = scene ? hx : -3e38f, uy = scene ? hy : -3e38f, uz = scene ? hz : -3e38f;
@@ -2480,10 +2545,10 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_beam(const DNode *__restrict_
                 __builtin_amdgcn_wave_barrier();
                 // ---- the walk: groups of children by content box, leaves chunk by chunk, triangle by triangle
                 bool blocked = false;
-                int sp = 0;
+                int sp = 0, budget = RT_BEAM_BUDGET;
                 if (root.count_flags & RT_NODE_LEAF) {
                     blocked = (root.count_flags & 0x7fffffffu) != 0u &&
-                              beam_leaf(uniform_u32(root.first), uniform_u32(root.count_flags) & 0x7fffffffu, uniform_u32(root.pad[0]), tris, chunks, lane, shaft, rec, SC);
+                              beam_leaf(uniform_u32(root.first), uniform_u32(root.count_flags) & 0x7fffffffu, uniform_u32(root.pad[0]), tris, chunks, lane, shaft, rec, SC, per_item, budget);
                 } else if ((root.count_flags & 0xfu) != 0u) {
                     if (lane == 0) stack[0] = root.first | ((root.count_flags & 0xfu) << 28);
                     sp = 1;
@@ -2497,8 +2562,10 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_beam(const DNode *__restrict_
                     const ShaftLanes SLg = shaft_lanes_load(shaft, tk, SC);
                     bool c_near, c_far;
                     shaft_lane_test(SLg, tk, ch.clo[0] - SC.pad, ch.clo[1] - SC.pad, ch.clo[2] - SC.pad, ch.chi[0] + SC.pad, ch.chi[1] + SC.pad, ch.chi[2] + SC.pad, c_near, c_far);
-                    const unsigned long long b_c = __ballot(c_near && ch.pad[1] == 0u);
+                    // (per_item: the content box bounds the cullable chunks below; the others are tested per hit afterwards)
+                    const unsigned long long b_c = __ballot(c_near && (ch.pad[1] == 0u || per_item));
                     unsigned long long surv = __ballot(static_cast<uint32_t>(lane) < gcnt && !ballot_byte_any(b_c, lane));
+                    if (--budget < 0) blocked = true;
                     while (surv != 0ull && !blocked) {
                         const int j = static_cast<int>(__builtin_ctzll(surv));
                         surv &= surv - 1ull;
@@ -2506,16 +2573,61 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_beam(const DNode *__restrict_
                         const uint32_t ff = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.first), 8 * j));
                         if (cf & RT_NODE_LEAF) {
                             const uint32_t lc = cf & 0x7fffffffu;
-                            if (lc != 0u) blocked = beam_leaf(ff, lc, static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.pad[0]), 8 * j)), tris, chunks, lane, shaft, rec, SC);
+                            if (lc != 0u) blocked = beam_leaf(ff, lc, static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.pad[0]), 8 * j)), tris, chunks, lane, shaft, rec, SC, per_item, budget);
                         } else if ((cf & 0xfu) != 0u) {
                             if (lane == 0) stack[sp] = ff | ((cf & 0xfu) << 28);
                             ++sp;
                         }
                     }
                 }
-                RT_PROF_ADD(lane, 76, 1); RT_PROF_ADD(lane, 77, blocked ? 0 : 1);
+                RT_PROF_ADD(lane, 76, 1); RT_PROF_ADD(lane, 77, blocked ? 0 : 1); RT_PROF_ADD(lane, 80, blocked ? 0 : RT_BEAM_BUDGET - budget); RT_PROF_ADD(lane, 81, budget < 0 ? 1 : 0);
+                if (brake && lane == 0) { atomicAdd(&yield[0], 1u); if (!blocked) atomicAdd(&yield[1], 1u); }
+                // the leaves with a chunk that may never be culled (degenerate triangles whose computed barycentrics are noise): can a ray to
+                // THIS hit -- or its continuation behind the hit -- enter the leaf's own box?  Lane-local shaft of (S, h): if the padded box is
+                // outside the near shaft by one plane AND outside the far cone by one, the reference's boxIntersect fails for every
+                // sample ray of the hit by a margin far above its rounding, so that leaf is never looked at for it.  (Not valid with a zero
+                // direction component: 0/0 = NaN makes the reference's min/max chain accept -- such hits stay with the shadow units.)
+                bool reach = false;
+                if (!blocked && per_item && S.n_bad_leaves != 0u) {
+                    bool dirs_ok = fabsf(hx) + fabsf(hy) + fabsf(hz) < 1e30f;
+                    if (L.mode == RT_LIGHT_SPHERE) {
+                        for (uint32_t k = 0u; k < N; ++k) {
+                            float sx, sy, sz;
+                            sphere_sample(L, k, px, py, pz, sx, sy, sz);
+                            dirs_ok = dirs_ok && (hx - sx != 0.0f) && (hy - sy != 0.0f) && (hz - sz != 0.0f);
+                        }
+                    } else {
+                        float sx, sy, sz;
+                        for (int i = 0; i < L.usteps; ++i) { grid_sample(lg, static_cast<float>(i) + 0.5f, 0.5f, sx, sy, sz); dirs_ok = dirs_ok && (hx - sx != 0.0f); }
+                        for (int j = 0; j < L.vsteps; ++j) { grid_sample(lg, 0.5f, static_cast<float>(j) + 0.5f, sx, sy, sz); dirs_ok = dirs_ok && (hy - sy != 0.0f); }
+                        dirs_ok = dirs_ok && (hz - sz != 0.0f);
+                    }
+                    const float big = fmaxf(fmaxf(fabsf(slx), fabsf(shx)), fmaxf(fabsf(sly), fabsf(shy))) + fmaxf(fabsf(slz), fabsf(shz));
+                    const float scale = S.extent + big + (fabsf(hx) + fabsf(hy) + fabsf(hz));
+                    const float pad = 4e-4f * ((fmaxf(fabsf(slx), fabsf(shx)) + fmaxf(fabsf(sly), fabsf(shy)) + fmaxf(fabsf(slz), fabsf(shz))) + S.extent) * 1.001f;
+                    const ItemPlane p0 = item_plane<0, false>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale), p1 = item_plane<0, true>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale);
+                    const ItemPlane p2 = item_plane<1, false>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale), p3 = item_plane<1, true>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale);
+                    const ItemPlane p4 = item_plane<2, false>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale), p5 = item_plane<2, true>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale);
+                    // near box: AABB of hull(S, h); far box: AABB of the far cone { h + tau (h - s) }
+                    const float nlx = fminf(slx, hx), nly = fminf(sly, hy), nlz = fminf(slz, hz), nhx = fmaxf(shx, hx), nhy = fmaxf(shy, hy), nhz = fmaxf(shz, hz);
+                    const float flx = hx >= shx ? hx : -3e38f, fly = hy >= shy ? hy : -3e38f, flz = hz >= shz ? hz : -3e38f;
+                    const float fhx = hx <= slx ? hx : 3e38f, fhy = hy <= sly ? hy : 3e38f, fhz = hz <= slz ? hz : 3e38f;
+                    for (uint32_t b = 0u; b < S.n_bad_leaves; ++b) {
+                        const float *bb = S.bad_leaves + 6u * b;
+                        const float lx_ = bb[0] - pad, ly_ = bb[1] - pad, lz_ = bb[2] - pad, hx_ = bb[3] + pad, hy_ = bb[4] + pad, hz_ = bb[5] + pad;
+                        bool near_out = (lx_ > nhx) || (hx_ < nlx) || (ly_ > nhy) || (hy_ < nly) || (lz_ > nhz) || (hz_ < nlz);
+                        bool far_out = (lx_ > fhx) || (hx_ < flx) || (ly_ > fhy) || (hy_ < fly) || (lz_ > fhz) || (hz_ < flz);
+                        item_plane_test<0>(p0, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out); item_plane_test<0>(p1, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out);
+                        item_plane_test<1>(p2, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out); item_plane_test<1>(p3, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out);
+                        item_plane_test<2>(p4, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out); item_plane_test<2>(p5, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out);
+                        reach = reach || !(dirs_ok && near_out && far_out);
+                    }
+                    RT_PROF_ADD(lane, 78, __popcll(__ballot(scene))); RT_PROF_ADD(lane, 79, __popcll(__ballot(scene && reach)));
+                }
                 if (blocked) {
                     survive = survive || scene;
+                } else if (scene && reach) {
+                    survive = true;
                 } else if (scene) {
                     // nothing can block any sample segment of these hits to light l: all N samples visible
                     const unsigned long long slot0 = (static_cast<unsigned long long>(idx) * static_cast<unsigned long long>(lslots) + static_cast<unsigned long long>(l)) * P;
