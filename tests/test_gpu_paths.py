@@ -345,3 +345,31 @@ def test_gpu_octree_build_of_the_1m_triangle_scene_and_after_a_model_change(rt, 
     for k in a:
         assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
     ctx.close(); cpu.close(); gpu.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,u,trees", [("cube.obj", 8, False), ("cube.obj", 16, False), ("toy.obj", 8, False), ("dodgeColorTest.obj", 8, True), ("dodgeColorTest.obj", 16, True)])
+def test_beam_test_of_whole_tiles_is_exact(rt, oracle, scene, u, trees, monkeypatch):
+    """k_beam decides whole tiles of 64 lit hits before a shadow ray exists (flat scenes by default, trees with RT_BEAM_TREES=1): the frame
+    must be the oracle's bit for bit, at one 64-sample word per (hit, light) and at four (16 x 16 samples: the words of all passes are
+    written by the beam), and equal to the frame without the beam test (RT_NO_BEAM=1).  On dodgeColorTest.obj this also runs the per-hit
+    test of the leaves that hold its degenerate triangles."""
+    if trees:
+        monkeypatch.setenv("RT_BEAM_TREES", "1")
+    path = os.path.join(SCENES, scene)
+    w, h, depth = 208, 136, 3
+    cam, ocam = rt.default_camera(w, h), oracle.camera(w, h)
+    L, oL = rt.make_lights(area=True, usteps=u, vsteps=u), oracle.lights(area=True, usteps=u, vsteps=u)
+    hs = rt.HostScene(path, 1000, 15)
+    ctx = rt.Context(0)
+    ctx.upload(hs)
+    rgb, hits = render_gpu(rt, ctx, cam, L, w, h, depth)
+    osc = oracle.load_scene(path)
+    ref, rhits, _ = osc.render(ocam, oL, w, h, max_depth=depth, threads=8, want_hits=True)
+    assert_exact(oracle, rgb, hits, ref, rhits)
+    monkeypatch.setenv("RT_NO_BEAM", "1")
+    ctx2 = rt.Context(0)
+    ctx2.upload(hs)
+    rgb2, hits2 = render_gpu(rt, ctx2, cam, L, w, h, depth)
+    assert np.array_equal(hits, hits2) and np.array_equal(rgb.view(np.uint32), rgb2.view(np.uint32))
+    osc.close(); ctx.close(); ctx2.close(); hs.close()

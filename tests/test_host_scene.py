@@ -200,3 +200,19 @@ def test_octree_growth_guard_and_lost_faces(rt, oracle, scenes):
     assert lib.rt_host_scene_load(path.encode(), 64, 15, C.byref(h)) == rt.capi.RT_ERR_UNSUPPORTED
     hs.close()
     osc.close()
+
+
+def test_chunk_bounds_skip_triangles_the_reference_can_never_accept(rt, scenes):
+    import ctypes as C
+    """dodgeColorTest.obj has 15 collinear triangles.  Four of them can never be accepted by rayTriangleIntersection as the reference
+    computes it (three have a zero face normal: dn == 0 for every ray; one has a float denominator of exactly 0: 1/denom = inf): they need
+    no bound, so the chunks that hold only such triangles stay cullable.  The other eleven (a denominator that is one rounding error
+    instead of zero: their barycentrics are noise) keep their chunks un-cullable.  CPU only: the counts rt_upload_scene works from."""
+    lib = rt.load_library()
+    hs = rt.HostScene(os.path.join(scenes, "dodgeColorTest.obj"), 1000, 15)
+    out = (C.c_int32 * 4)()
+    assert lib.rt_debug_chunk_stats(C.byref(hs.view), out) == 0
+    chunks, cullable = out[0], out[1]
+    never = chunks - cullable
+    assert chunks > 400 and 0 < never < 23, (chunks, cullable)         # 23 when every collinear triangle counted; the live ones sit in 22 chunks
+    hs.close()
