@@ -182,7 +182,7 @@ def test_sphere_offsets_host_equals_oracle(rt, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scene,n", [("cube.obj", 25), ("dodgeColorTest.obj", 25), ("dodgeColorTest.obj", 64)])
+@pytest.mark.parametrize("scene,n", [("cube.obj", 25), ("cube.obj", 64), ("dodgeColorTest.obj", 25), ("dodgeColorTest.obj", 64)])
 def test_spherical_light_mode_matches_oracle(rt, oracle, scene, n):
     """createSpherePoint's third branch (flyscene.cpp:974-995) with seeded offsets: 25 samples (two (hit, light) pairs per wave) and 64
     (the shaft walk), mirror bounces included (the child's light list is {hitPoint}: its samples are offsets + hitPoint)."""
