@@ -690,13 +690,13 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
         }
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
         launch_set_prof(st, c->d_ctl, RT_WORK_SHADOW);
-        // one (hit, light) pair per wave (N > 32 samples): first the beam test of whole tiles of 64 hits (k_beam: the hits whose sample rays
-        // nothing can block get their visibility words there and never become shadow units), then the survivors
+        // first the beam test of whole tiles of 64 hits (k_beam: the hits whose sample rays nothing can block get their visibility words
+        // there and never become shadow units), then the survivors
         // (tree scenes: off unless RT_BEAM_TREES=1.  Measured on dodgeColorTest.obj 1080p/64: 84 % of the 3,332 tiles come out unblocked -- none
         // of their hits can reach a leaf with one of the model's degenerate triangles -- and the shadow units drop from 213k to 33k, but a beam
         // walks ~370 steps alone in its wave (k_beam 0.30 ms) and the units that remain are the expensive ones (penumbra, cluttered parts:
         // 0.60 ms of the former 0.77): 0.90 ms against 0.77.  cfg4: 9 % unblocked; the launch's own brake stops testing after 4k of 18k tiles.)
-        const bool beam = !count && c->S.beam != 0 && L.n_samples > 32 && (c->flat || c->beam_trees);
+        const bool beam = !count && c->S.beam != 0 && (c->flat || c->beam_trees);
         const uint32_t *sidx = beam ? c->d_sidx : nullptr;
         if (beam) launch_beam(c->cus * 4, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_sidx);
         // tree scenes with one (hit, light) pair per wave: the shaft walk (rt_kernels.hip, k_shadow_shaft)
