@@ -2463,6 +2463,173 @@ __device__ __forceinline__ bool beam_leaf(const uint32_t first, const uint32_t c
     return false;
 }
 
+// One tile of lit hits (lane = hit: `have`, its item storage index, hit point and light mode) through the beam test: writes the visibility
+// words of the hits nothing can block, appends the others to the survivor list, accounts the sample rays of the former.
+struct BeamCtx {
+    const DNode *nodes; const TriRec *tris; const ChunkBound *chunks;
+    uint32_t *stack; float4 *rec; float4 *shaft;           // per-wave LDS
+    uint32_t *yield; bool brake, per_item, blocks;
+    uint32_t N, P, item_cap; int lslots, level;
+    float fi_last, fj_last;
+};
+__device__ __forceinline__ void beam_tile(const BeamCtx &B, const DScene &S, const DLights &L, const DNode &root, Control *__restrict__ ctl,
+                                          unsigned long long *__restrict__ vis, uint32_t *__restrict__ sidx, const int lane, const uint32_t tile,
+                                          const bool have, const uint32_t idx, const float hx, const float hy, const float hz, const uint32_t lmode, uint32_t &c_rays) {
+    const DNode *__restrict__ nodes = B.nodes; const TriRec *__restrict__ tris = B.tris; const ChunkBound *__restrict__ chunks = B.chunks;
+    uint32_t *const stack = B.stack; float4 *const rec = B.rec; float4 *const shaft = B.shaft; uint32_t *const yield = B.yield;
+    const bool brake = B.brake, per_item = B.per_item, blocks = B.blocks;
+    const uint32_t N = B.N, P = B.P, item_cap = B.item_cap;
+    const int lslots = B.lslots, level = B.level;
+    const float fi_last = B.fi_last, fj_last = B.fj_last;
+    const int tk = lane & 7, tc = lane >> 3;
+    const bool scene = have && lmode == 0u;              // sees the scene lights (a mirror bounce carries a light list of its own)
+    bool survive = have && !scene;
+    const unsigned long long sm0 = __ballot(scene);
+    bool give_up = false;
+    if (brake) {
+        const uint32_t y_t = uniform_u32(__hip_atomic_load(&yield[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const uint32_t y_u = uniform_u32(__hip_atomic_load(&yield[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        give_up = y_t >= 16u && y_u * 4u < y_t;
+    }
+    if (give_up) survive = have;
+    if (sm0 != 0ull && !give_up) {
+        // H: exact wave min / max of the hit points
+        float lx = scene ? hx : 3e38f, ly = scene ? hy : 3e38f, lz = scene ? hz : 3e38f;
+        float ux = scene ? hx : -3e38f, uy = scene ? hy : -3e38f, uz = scene ? hz : -3e38f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64)); lz = fminf(lz, __shfl_xor(lz, o, 64));
+            ux = fmaxf(ux, __shfl_xor(ux, o, 64)); uy = fmaxf(uy, __shfl_xor(uy, o, 64)); uz = fmaxf(uz, __shfl_xor(uz, o, 64));
+        }
+        const float cx = 0.5f * (lx + ux), cy = 0.5f * (ly + uy), cz = 0.5f * (lz + uz);
+        // half extent around the ROUNDED centre, rounded up
+        const float ex = fmaxf(ux - cx, cx - lx) * 1.0001f + 1e-7f * S.extent, ey = fmaxf(uy - cy, cy - ly) * 1.0001f + 1e-7f * S.extent,
+                    ez = fmaxf(uz - cz, cz - lz) * 1.0001f + 1e-7f * S.extent;
+        for (int l = 0; l < L.n_lights; ++l) {
+            float x0, y0, z0, x1, y1, z1;
+            const float px = L.pos[l][0], py = L.pos[l][1], pz = L.pos[l][2];
+            const LightGrid lg = light_grid(L, px, py, pz);
+            grid_sample(lg, 0.5f, 0.5f, x0, y0, z0);             // the samples are monotone in each grid index: two corners give the exact box
+            grid_sample(lg, fi_last, fj_last, x1, y1, z1);
+            if (L.mode == RT_LIGHT_SPHERE) sphere_box(L, px, py, pz, x0, y0, z0, x1, y1, z1);
+            const float slx = fminf(x0, x1), sly = fminf(y0, y1), slz = fminf(z0, z1), shx = fmaxf(x0, x1), shy = fmaxf(y0, y1), shz = fmaxf(z0, z1);
+            ShaftLanes SL = make_shaft_lanes(lane, cx, cy, cz, slx, sly, slz, shx, shy, shz, S.extent);
+            shaft_inflate(SL, tk, ex, ey, ez);
+            const ShaftCtl SC{SL.pad, false};
+            __builtin_amdgcn_wave_barrier();
+            shaft_tri_store(rec, lane, SL, cx, cy, cz, slx, sly, slz, shx, shy, shz);
+            shaft_lanes_store(shaft, lane, SL);
+            if (lane == 8) {
+                const float m0 = 2e-5f * (((fabsf(slx) + fabsf(shx)) + (fabsf(sly) + fabsf(shy)) + (fabsf(slz) + fabsf(shz))) +
+                                          ((fabsf(lx) + fabsf(ux)) + (fabsf(ly) + fabsf(uy)) + (fabsf(lz) + fabsf(uz))));
+                rec[8] = make_float4(cx, cy, cz, m0); rec[11] = make_float4(lx, ly, lz, 0.f); rec[12] = make_float4(ux, uy, uz, 0.f);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- the walk: groups of children by content box, leaves chunk by chunk, triangle by triangle
+            bool blocked = false;
+            int sp = 0, budget = RT_BEAM_BUDGET;
+            if (root.count_flags & RT_NODE_LEAF) {
+                blocked = (root.count_flags & 0x7fffffffu) != 0u &&
+                          beam_leaf(uniform_u32(root.first), uniform_u32(root.count_flags) & 0x7fffffffu, uniform_u32(root.pad[0]), tris, chunks, lane, shaft, rec, SC, per_item, budget);
+            } else if ((root.count_flags & 0xfu) != 0u) {
+                if (lane == 0) stack[0] = root.first | ((root.count_flags & 0xfu) << 28);
+                sp = 1;
+            }
+            while (sp > 0 && !blocked) {
+                --sp;
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t ent = uniform_u32(stack[sp]);
+                const uint32_t base = ent & 0x0fffffffu, gcnt = ent >> 28;
+                const DNode ch = nodes[base + (static_cast<uint32_t>(tc) < gcnt ? static_cast<uint32_t>(tc) : 0u)];
+                const ShaftLanes SLg = shaft_lanes_load(shaft, tk, SC);
+                bool c_near, c_far;
+                shaft_lane_test(SLg, tk, ch.clo[0] - SC.pad, ch.clo[1] - SC.pad, ch.clo[2] - SC.pad, ch.chi[0] + SC.pad, ch.chi[1] + SC.pad, ch.chi[2] + SC.pad, c_near, c_far);
+                // (per_item: the content box bounds the cullable chunks below; the others are tested per hit afterwards)
+                const unsigned long long b_c = __ballot(c_near && (ch.pad[1] == 0u || per_item));
+                unsigned long long surv = __ballot(static_cast<uint32_t>(lane) < gcnt && !ballot_byte_any(b_c, lane));
+                if (--budget < 0) blocked = true;
+                while (surv != 0ull && !blocked) {
+                    const int j = static_cast<int>(__builtin_ctzll(surv));
+                    surv &= surv - 1ull;
+                    const uint32_t cf = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.count_flags), 8 * j));
+                    const uint32_t ff = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.first), 8 * j));
+                    if (cf & RT_NODE_LEAF) {
+                        const uint32_t lc = cf & 0x7fffffffu;
+                        if (lc != 0u) blocked = beam_leaf(ff, lc, static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.pad[0]), 8 * j)), tris, chunks, lane, shaft, rec, SC, per_item, budget);
+                    } else if ((cf & 0xfu) != 0u) {
+                        if (lane == 0) stack[sp] = ff | ((cf & 0xfu) << 28);
+                        ++sp;
+                    }
+                }
+            }
+            RT_PROF_ADD(lane, 76, 1); RT_PROF_ADD(lane, 77, blocked ? 0 : 1); RT_PROF_ADD(lane, 80, blocked ? 0 : RT_BEAM_BUDGET - budget); RT_PROF_ADD(lane, 81, budget < 0 ? 1 : 0);
+            if (brake && lane == 0) { atomicAdd(&yield[0], 1u); if (!blocked) atomicAdd(&yield[1], 1u); }
+            // the leaves with a chunk that may never be culled (degenerate triangles whose computed barycentrics are noise): can a ray to
+            // THIS hit -- or its continuation behind the hit -- enter the leaf's own box?  Lane-local shaft of (S, h): if the padded box is
+            // outside the near shaft by one plane AND outside the far cone by one, the reference's boxIntersect fails for every
+            // sample ray of the hit by a margin far above its rounding, so that leaf is never looked at for it.  (Not valid with a zero
+            // direction component: 0/0 = NaN makes the reference's min/max chain accept -- such hits stay with the shadow units.)
+            bool reach = false;
+            if (!blocked && per_item && S.n_bad_leaves != 0u) {
+                bool dirs_ok = fabsf(hx) + fabsf(hy) + fabsf(hz) < 1e30f;
+                if (L.mode == RT_LIGHT_SPHERE) {
+                    for (uint32_t k = 0u; k < N; ++k) {
+                        float sx, sy, sz;
+                        sphere_sample(L, k, px, py, pz, sx, sy, sz);
+                        dirs_ok = dirs_ok && (hx - sx != 0.0f) && (hy - sy != 0.0f) && (hz - sz != 0.0f);
+                    }
+                } else {
+                    float sx, sy, sz;
+                    for (int i = 0; i < L.usteps; ++i) { grid_sample(lg, static_cast<float>(i) + 0.5f, 0.5f, sx, sy, sz); dirs_ok = dirs_ok && (hx - sx != 0.0f); }
+                    for (int j = 0; j < L.vsteps; ++j) { grid_sample(lg, 0.5f, static_cast<float>(j) + 0.5f, sx, sy, sz); dirs_ok = dirs_ok && (hy - sy != 0.0f); }
+                    dirs_ok = dirs_ok && (hz - sz != 0.0f);
+                }
+                const float big = fmaxf(fmaxf(fabsf(slx), fabsf(shx)), fmaxf(fabsf(sly), fabsf(shy))) + fmaxf(fabsf(slz), fabsf(shz));
+                const float scale = S.extent + big + (fabsf(hx) + fabsf(hy) + fabsf(hz));
+                const float pad = 4e-4f * ((fmaxf(fabsf(slx), fabsf(shx)) + fmaxf(fabsf(sly), fabsf(shy)) + fmaxf(fabsf(slz), fabsf(shz))) + S.extent) * 1.001f;
+                const ItemPlane p0 = item_plane<0, false>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale), p1 = item_plane<0, true>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale);
+                const ItemPlane p2 = item_plane<1, false>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale), p3 = item_plane<1, true>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale);
+                const ItemPlane p4 = item_plane<2, false>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale), p5 = item_plane<2, true>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale);
+                // near box: AABB of hull(S, h); far box: AABB of the far cone { h + tau (h - s) }
+                const float nlx = fminf(slx, hx), nly = fminf(sly, hy), nlz = fminf(slz, hz), nhx = fmaxf(shx, hx), nhy = fmaxf(shy, hy), nhz = fmaxf(shz, hz);
+                const float flx = hx >= shx ? hx : -3e38f, fly = hy >= shy ? hy : -3e38f, flz = hz >= shz ? hz : -3e38f;
+                const float fhx = hx <= slx ? hx : 3e38f, fhy = hy <= sly ? hy : 3e38f, fhz = hz <= slz ? hz : 3e38f;
+                for (uint32_t b = 0u; b < S.n_bad_leaves; ++b) {
+                    const float *bb = S.bad_leaves + 6u * b;
+                    const float lx_ = bb[0] - pad, ly_ = bb[1] - pad, lz_ = bb[2] - pad, hx_ = bb[3] + pad, hy_ = bb[4] + pad, hz_ = bb[5] + pad;
+                    bool near_out = (lx_ > nhx) || (hx_ < nlx) || (ly_ > nhy) || (hy_ < nly) || (lz_ > nhz) || (hz_ < nlz);
+                    bool far_out = (lx_ > fhx) || (hx_ < flx) || (ly_ > fhy) || (hy_ < fly) || (lz_ > fhz) || (hz_ < flz);
+                    item_plane_test<0>(p0, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out); item_plane_test<0>(p1, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out);
+                    item_plane_test<1>(p2, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out); item_plane_test<1>(p3, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out);
+                    item_plane_test<2>(p4, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out); item_plane_test<2>(p5, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out);
+                    reach = reach || !(dirs_ok && near_out && far_out);
+                }
+                RT_PROF_ADD(lane, 78, __popcll(__ballot(scene))); RT_PROF_ADD(lane, 79, __popcll(__ballot(scene && reach)));
+            }
+            if (blocked) {
+                survive = survive || scene;
+            } else if (scene && reach) {
+                survive = true;
+            } else if (scene) {
+                // nothing can block any sample segment of these hits to light l: all N samples visible
+                const unsigned long long slot0 = (static_cast<unsigned long long>(idx) * static_cast<unsigned long long>(lslots) + static_cast<unsigned long long>(l)) * P;
+                for (uint32_t p = 0u; p < P; ++p) {
+                    const uint32_t left = N - p * 64u;
+                    vis[slot0 + p] = (blocks || left >= 64u) ? ~0ull : ((1ull << left) - 1ull);
+                }
+            }
+        }
+    }
+    // hits that need no shadow unit at all: their sample rays are accounted for here (the shadow kernels count the others)
+    c_rays += (have && !survive) ? N * static_cast<uint32_t>(L.n_lights) : 0u;
+    const unsigned long long sm = __ballot(survive);
+    if (sm != 0ull) {
+        bool fits;
+        const uint32_t at = shard_reserve(ctl->n_sitems[level], &ctl->overflow, tile, static_cast<uint32_t>(__popcll(sm)), item_cap, lane, fits);
+        if (survive && fits) sidx[at + lanes_below(sm)] = idx;
+    }
+}
+
 __global__ __launch_bounds__(RT_WAVES * 64) void k_beam(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris, const ChunkBound *__restrict__ chunks,
                                                         const DScene S, const DLights L, const int level, const int lslots, const uint32_t item_cap,
                                                         const ShadeItem *__restrict__ items, Control *__restrict__ ctl, unsigned long long *__restrict__ vis,
@@ -2481,7 +2648,6 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_beam(const DNode *__restrict_
     const uint32_t P = (N + 63u) / 64u;
     const bool blocks = sample_blocks(L);
     const DNode root = nodes[0];
-    const int tk = lane & 7, tc = lane >> 3;
     const float fi_last = static_cast<float>(L.usteps - 1) + 0.5f, fj_last = static_cast<float>(L.vsteps - 1) + 0.5f;
     const bool per_item = S.n_bad_leaves != 0xffffffffu;
     const bool brake = (root.count_flags & RT_NODE_LEAF) == 0u;      // (a flat scene is one leaf: always cheap to test, nothing to watch)
@@ -2493,6 +2659,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_beam(const DNode *__restrict_
     // that report to it pass their remaining tiles on untested.  The results do not depend on it -- an untested tile simply goes to the shadow kernels.
     uint32_t *const yield = ctl->beam_yield[level] + (blockIdx.x & (RT_LIST_SHARDS - 1u)) * 16u;      // this workgroup's shard (one returning or
                                                                                                       // non-returning atomic word takes ~88 updates per microsecond)
+    const BeamCtx B{nodes, tris, chunks, stack, rec, shaft, yield, brake, per_item, blocks, N, P, item_cap, lslots, level, fi_last, fj_last};
     for (uint32_t tile = wave_id; tile < ntiles; tile += wave_count) {
         uint32_t sh, tj, n_sh;
         shard_find(imap, tile, sh, tj, n_sh);
@@ -2500,152 +2667,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_beam(const DNode *__restrict_
         const uint32_t idx = sh * item_cap + tj * 64u + static_cast<uint32_t>(lane);     // item storage index (also keys vis)
         const ShadeItem it = items[have ? idx : sh * item_cap];
         const float hx = it.ox + it.t * it.dx, hy = it.oy + it.t * it.dy, hz = it.oz + it.t * it.dz;      // as the shadow kernels form it
-        const bool scene = have && it.lmode == 0u;              // sees the scene lights (a mirror bounce carries a light list of its own)
-        bool survive = have && !scene;
-        const unsigned long long sm0 = __ballot(scene);
-        bool give_up = false;
-        if (brake) {
-            const uint32_t y_t = uniform_u32(__hip_atomic_load(&yield[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            const uint32_t y_u = uniform_u32(__hip_atomic_load(&yield[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            give_up = y_t >= 16u && y_u * 4u < y_t;
-        }
-        if (give_up) survive = have;
-        if (sm0 != 0ull && !give_up) {
-            // H: exact wave min / max of the hit points
-            float lx = scene ? hx : 3e38f, ly = scene ? hy : 3e38f, lz = scene ? hz : 3e38f;
-            float ux = scene ? hx : -3e38f, uy = scene ? hy : -3e38f, uz = scene ? hz : -3e38f;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                lx = fminf(lx, __shfl_xor(lx, o, 64)); ly = fminf(ly, __shfl_xor(ly, o, 64)); lz = fminf(lz, __shfl_xor(lz, o, 64));
-                ux = fmaxf(ux, __shfl_xor(ux, o, 64)); uy = fmaxf(uy, __shfl_xor(uy, o, 64)); uz = fmaxf(uz, __shfl_xor(uz, o, 64));
-            }
-            const float cx = 0.5f * (lx + ux), cy = 0.5f * (ly + uy), cz = 0.5f * (lz + uz);
-            // half extent around the ROUNDED centre, rounded up
-            const float ex = fmaxf(ux - cx, cx - lx) * 1.0001f + 1e-7f * S.extent, ey = fmaxf(uy - cy, cy - ly) * 1.0001f + 1e-7f * S.extent,
-                        ez = fmaxf(uz - cz, cz - lz) * 1.0001f + 1e-7f * S.extent;
-            for (int l = 0; l < L.n_lights; ++l) {
-                float x0, y0, z0, x1, y1, z1;
-                const float px = L.pos[l][0], py = L.pos[l][1], pz = L.pos[l][2];
-                const LightGrid lg = light_grid(L, px, py, pz);
-                grid_sample(lg, 0.5f, 0.5f, x0, y0, z0);             // the samples are monotone in each grid index: two corners give the exact box
-                grid_sample(lg, fi_last, fj_last, x1, y1, z1);
-                if (L.mode == RT_LIGHT_SPHERE) sphere_box(L, px, py, pz, x0, y0, z0, x1, y1, z1);
-                const float slx = fminf(x0, x1), sly = fminf(y0, y1), slz = fminf(z0, z1), shx = fmaxf(x0, x1), shy = fmaxf(y0, y1), shz = fmaxf(z0, z1);
-                ShaftLanes SL = make_shaft_lanes(lane, cx, cy, cz, slx, sly, slz, shx, shy, shz, S.extent);
-                shaft_inflate(SL, tk, ex, ey, ez);
-                const ShaftCtl SC{SL.pad, false};
-                __builtin_amdgcn_wave_barrier();
-                shaft_tri_store(rec, lane, SL, cx, cy, cz, slx, sly, slz, shx, shy, shz);
-                shaft_lanes_store(shaft, lane, SL);
-                if (lane == 8) {
-                    const float m0 = 2e-5f * (((fabsf(slx) + fabsf(shx)) + (fabsf(sly) + fabsf(shy)) + (fabsf(slz) + fabsf(shz))) +
-                                              ((fabsf(lx) + fabsf(ux)) + (fabsf(ly) + fabsf(uy)) + (fabsf(lz) + fabsf(uz))));
-                    rec[8] = make_float4(cx, cy, cz, m0); rec[11] = make_float4(lx, ly, lz, 0.f); rec[12] = make_float4(ux, uy, uz, 0.f);
-                }
-                __builtin_amdgcn_wave_barrier();
-                // ---- the walk: groups of children by content box, leaves chunk by chunk, triangle by triangle
-                bool blocked = false;
-                int sp = 0, budget = RT_BEAM_BUDGET;
-                if (root.count_flags & RT_NODE_LEAF) {
-                    blocked = (root.count_flags & 0x7fffffffu) != 0u &&
-                              beam_leaf(uniform_u32(root.first), uniform_u32(root.count_flags) & 0x7fffffffu, uniform_u32(root.pad[0]), tris, chunks, lane, shaft, rec, SC, per_item, budget);
-                } else if ((root.count_flags & 0xfu) != 0u) {
-                    if (lane == 0) stack[0] = root.first | ((root.count_flags & 0xfu) << 28);
-                    sp = 1;
-                }
-                while (sp > 0 && !blocked) {
-                    --sp;
-                    __builtin_amdgcn_wave_barrier();
-                    const uint32_t ent = uniform_u32(stack[sp]);
-                    const uint32_t base = ent & 0x0fffffffu, gcnt = ent >> 28;
-                    const DNode ch = nodes[base + (static_cast<uint32_t>(tc) < gcnt ? static_cast<uint32_t>(tc) : 0u)];
-                    const ShaftLanes SLg = shaft_lanes_load(shaft, tk, SC);
-                    bool c_near, c_far;
-                    shaft_lane_test(SLg, tk, ch.clo[0] - SC.pad, ch.clo[1] - SC.pad, ch.clo[2] - SC.pad, ch.chi[0] + SC.pad, ch.chi[1] + SC.pad, ch.chi[2] + SC.pad, c_near, c_far);
-                    // (per_item: the content box bounds the cullable chunks below; the others are tested per hit afterwards)
-                    const unsigned long long b_c = __ballot(c_near && (ch.pad[1] == 0u || per_item));
-                    unsigned long long surv = __ballot(static_cast<uint32_t>(lane) < gcnt && !ballot_byte_any(b_c, lane));
-                    if (--budget < 0) blocked = true;
-                    while (surv != 0ull && !blocked) {
-                        const int j = static_cast<int>(__builtin_ctzll(surv));
-                        surv &= surv - 1ull;
-                        const uint32_t cf = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.count_flags), 8 * j));
-                        const uint32_t ff = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.first), 8 * j));
-                        if (cf & RT_NODE_LEAF) {
-                            const uint32_t lc = cf & 0x7fffffffu;
-                            if (lc != 0u) blocked = beam_leaf(ff, lc, static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.pad[0]), 8 * j)), tris, chunks, lane, shaft, rec, SC, per_item, budget);
-                        } else if ((cf & 0xfu) != 0u) {
-                            if (lane == 0) stack[sp] = ff | ((cf & 0xfu) << 28);
-                            ++sp;
-                        }
-                    }
-                }
-                RT_PROF_ADD(lane, 76, 1); RT_PROF_ADD(lane, 77, blocked ? 0 : 1); RT_PROF_ADD(lane, 80, blocked ? 0 : RT_BEAM_BUDGET - budget); RT_PROF_ADD(lane, 81, budget < 0 ? 1 : 0);
-                if (brake && lane == 0) { atomicAdd(&yield[0], 1u); if (!blocked) atomicAdd(&yield[1], 1u); }
-                // the leaves with a chunk that may never be culled (degenerate triangles whose computed barycentrics are noise): can a ray to
-                // THIS hit -- or its continuation behind the hit -- enter the leaf's own box?  Lane-local shaft of (S, h): if the padded box is
-                // outside the near shaft by one plane AND outside the far cone by one, the reference's boxIntersect fails for every
-                // sample ray of the hit by a margin far above its rounding, so that leaf is never looked at for it.  (Not valid with a zero
-                // direction component: 0/0 = NaN makes the reference's min/max chain accept -- such hits stay with the shadow units.)
-                bool reach = false;
-                if (!blocked && per_item && S.n_bad_leaves != 0u) {
-                    bool dirs_ok = fabsf(hx) + fabsf(hy) + fabsf(hz) < 1e30f;
-                    if (L.mode == RT_LIGHT_SPHERE) {
-                        for (uint32_t k = 0u; k < N; ++k) {
-                            float sx, sy, sz;
-                            sphere_sample(L, k, px, py, pz, sx, sy, sz);
-                            dirs_ok = dirs_ok && (hx - sx != 0.0f) && (hy - sy != 0.0f) && (hz - sz != 0.0f);
-                        }
-                    } else {
-                        float sx, sy, sz;
-                        for (int i = 0; i < L.usteps; ++i) { grid_sample(lg, static_cast<float>(i) + 0.5f, 0.5f, sx, sy, sz); dirs_ok = dirs_ok && (hx - sx != 0.0f); }
-                        for (int j = 0; j < L.vsteps; ++j) { grid_sample(lg, 0.5f, static_cast<float>(j) + 0.5f, sx, sy, sz); dirs_ok = dirs_ok && (hy - sy != 0.0f); }
-                        dirs_ok = dirs_ok && (hz - sz != 0.0f);
-                    }
-                    const float big = fmaxf(fmaxf(fabsf(slx), fabsf(shx)), fmaxf(fabsf(sly), fabsf(shy))) + fmaxf(fabsf(slz), fabsf(shz));
-                    const float scale = S.extent + big + (fabsf(hx) + fabsf(hy) + fabsf(hz));
-                    const float pad = 4e-4f * ((fmaxf(fabsf(slx), fabsf(shx)) + fmaxf(fabsf(sly), fabsf(shy)) + fmaxf(fabsf(slz), fabsf(shz))) + S.extent) * 1.001f;
-                    const ItemPlane p0 = item_plane<0, false>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale), p1 = item_plane<0, true>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale);
-                    const ItemPlane p2 = item_plane<1, false>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale), p3 = item_plane<1, true>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale);
-                    const ItemPlane p4 = item_plane<2, false>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale), p5 = item_plane<2, true>(hx, hy, hz, slx, sly, slz, shx, shy, shz, scale);
-                    // near box: AABB of hull(S, h); far box: AABB of the far cone { h + tau (h - s) }
-                    const float nlx = fminf(slx, hx), nly = fminf(sly, hy), nlz = fminf(slz, hz), nhx = fmaxf(shx, hx), nhy = fmaxf(shy, hy), nhz = fmaxf(shz, hz);
-                    const float flx = hx >= shx ? hx : -3e38f, fly = hy >= shy ? hy : -3e38f, flz = hz >= shz ? hz : -3e38f;
-                    const float fhx = hx <= slx ? hx : 3e38f, fhy = hy <= sly ? hy : 3e38f, fhz = hz <= slz ? hz : 3e38f;
-                    for (uint32_t b = 0u; b < S.n_bad_leaves; ++b) {
-                        const float *bb = S.bad_leaves + 6u * b;
-                        const float lx_ = bb[0] - pad, ly_ = bb[1] - pad, lz_ = bb[2] - pad, hx_ = bb[3] + pad, hy_ = bb[4] + pad, hz_ = bb[5] + pad;
-                        bool near_out = (lx_ > nhx) || (hx_ < nlx) || (ly_ > nhy) || (hy_ < nly) || (lz_ > nhz) || (hz_ < nlz);
-                        bool far_out = (lx_ > fhx) || (hx_ < flx) || (ly_ > fhy) || (hy_ < fly) || (lz_ > fhz) || (hz_ < flz);
-                        item_plane_test<0>(p0, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out); item_plane_test<0>(p1, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out);
-                        item_plane_test<1>(p2, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out); item_plane_test<1>(p3, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out);
-                        item_plane_test<2>(p4, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out); item_plane_test<2>(p5, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out);
-                        reach = reach || !(dirs_ok && near_out && far_out);
-                    }
-                    RT_PROF_ADD(lane, 78, __popcll(__ballot(scene))); RT_PROF_ADD(lane, 79, __popcll(__ballot(scene && reach)));
-                }
-                if (blocked) {
-                    survive = survive || scene;
-                } else if (scene && reach) {
-                    survive = true;
-                } else if (scene) {
-                    // nothing can block any sample segment of these hits to light l: all N samples visible
-                    const unsigned long long slot0 = (static_cast<unsigned long long>(idx) * static_cast<unsigned long long>(lslots) + static_cast<unsigned long long>(l)) * P;
-                    for (uint32_t p = 0u; p < P; ++p) {
-                        const uint32_t left = N - p * 64u;
-                        vis[slot0 + p] = (blocks || left >= 64u) ? ~0ull : ((1ull << left) - 1ull);
-                    }
-                }
-            }
-        }
-        // hits that need no shadow unit at all: their sample rays are accounted for here (the shadow kernels count the others)
-        c_rays += (have && !survive) ? N * static_cast<uint32_t>(L.n_lights) : 0u;
-        const unsigned long long sm = __ballot(survive);
-        if (sm != 0ull) {
-            bool fits;
-            const uint32_t at = shard_reserve(ctl->n_sitems[level], &ctl->overflow, tile, static_cast<uint32_t>(__popcll(sm)), item_cap, lane, fits);
-            if (survive && fits) sidx[at + lanes_below(sm)] = idx;
-        }
+        beam_tile(B, S, L, root, ctl, vis, sidx, lane, tile, have, idx, hx, hy, hz, it.lmode, c_rays);
     }
     c_rays = wave_sum(c_rays);
     if (lane == 0 && c_rays) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_SAMPLE], static_cast<unsigned long long>(c_rays));
