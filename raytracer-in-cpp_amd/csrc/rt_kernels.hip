@@ -1016,7 +1016,7 @@ struct ShaftLds {
 };
 
 // One leaf of the shaft walk.  Chunk bounds are shaft-tested 8 at a time (lane = (chunk, test)); what survives goes through the per-ray
-// chunk test (lane = ray) and the triangle tests (lane = triangle); the next chunk's records are loaded while the current one is processed.
+// chunk test (lane = ray) and the triangle tests (lane = triangle).
 // where a shaft walk hands big leaves to (the leaf-task queue of the k_shadow<.., CONT> launch that follows): budget 0 = never
 struct ShaftTasks {
     ContTask *tasks;
@@ -1128,9 +1128,6 @@ __device__ __forceinline__ void shaft_leaf(const uint32_t ni, const uint32_t fir
         if (cur < 0) continue;
         TriRec tr = load_chunk(cur);
         while (cur >= 0) {
-            const int nxt_j = find_next(todo_nxt);
-            TriRec nxt = tr;
-            if (nxt_j >= 0) nxt = load_chunk(nxt_j);
             const uint32_t c0 = (cb0 + static_cast<uint32_t>(cur)) * 64u;
             const uint32_t n = cnt - c0 < 64u ? cnt - c0 : 64u;
             bool hast = static_cast<uint32_t>(lane) < n && !(tr.flags & 1u);
@@ -1211,7 +1208,10 @@ __device__ __forceinline__ void shaft_leaf(const uint32_t ni, const uint32_t fir
             }
             RT_PH(sl, 3);
             if (live == 0ull) break;
-            cur = nxt_j; tr = nxt; todo_cur = todo_nxt;
+            // (the next chunk's records used to be requested before this one was worked on: twenty registers for one hidden round trip.
+            // Without them the kernel fits 80 registers -- six waves per SIMD cover the latency better: cfg4 -6 %, dodge -3 %)
+            cur = find_next(todo_nxt); todo_cur = todo_nxt;
+            if (cur >= 0) tr = load_chunk(cur);
         }
     }
     occluded = occluded || (((occ_new >> lane) & 1ull) != 0ull);
@@ -2126,8 +2126,11 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(F
 // K2 on TREE scenes with one (hit, light) pair -- or one 64-sample pass of it -- per wave (N >= 33 samples): the shaft walk.
 // Same units, same queue and same output words as k_shadow<false, false, false>.
 // ======================================================================================================
+#ifndef RT_SHAFT_WPE
+#define RT_SHAFT_WPE 6
+#endif
 template <bool CONT, bool TASKS>
-__global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(RT_SHADOW_WPE, 8)))
+__global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(RT_SHAFT_WPE, 8)))
 void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris, const ChunkBound *__restrict__ chunks,
                     const DScene S, const DLights L, const int level, const int ctr_slot, const int lslots, const uint32_t item_cap,
                     const ShadeItem *__restrict__ items, Control *__restrict__ ctl, unsigned long long *__restrict__ vis, const TaskQueues Q,
