@@ -40,7 +40,7 @@ void launch_box_probe(hipStream_t st, int n, const float *box, const float *org,
 void launch_tree_probe(int grid, hipStream_t st, const DScene &S, int n, const float *org, const float *dst, uint32_t *out_box, uint32_t *out_ref, uint32_t *out_sig);
 void launch_primary_probe(int grid, hipStream_t st, const DCam *cam, int W, int H, float *out);
 bool gpu_build_octree(HostScene &hs, int cap, int depth, hipStream_t st, std::string *err);
-void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow, int *shade);
+void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow, int *shaft, int *shade);
 void launch_set_prof(hipStream_t st, Control *ctl, uint32_t base);
 }  // namespace rtamd
 
@@ -53,7 +53,7 @@ struct rt_host_scene {
 struct rt_ctx {
     int device = 0;
     int cus = 256;
-    int occ_trace_primary = 4, occ_trace_rays = 4, occ_shadow = 4, occ_shade = 2;   // resident blocks per CU
+    int occ_trace_primary = 4, occ_trace_rays = 4, occ_shadow = 4, occ_shaft = 4, occ_shade = 2;   // resident blocks per CU
     hipStream_t stream = nullptr;
     std::string err;
     // scene
@@ -521,12 +521,12 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     c->S.beam = (no_cull || std::getenv("RT_NO_BEAM") != nullptr) ? 0 : 1;
     if (sc->n_nodes >= (1u << 28)) { c->err = "rt_upload_scene: more than 2^28 nodes"; return RT_ERR_UNSUPPORTED; }
     c->flat = (sc->nodes[0].count_flags & RT_NODE_LEAF) && (sc->nodes[0].count_flags & 0x7fffffffu) <= 64u;
-    query_occupancy(c->flat, &c->occ_trace_primary, &c->occ_trace_rays, &c->occ_shadow, &c->occ_shade);
+    query_occupancy(c->flat, &c->occ_trace_primary, &c->occ_trace_rays, &c->occ_shadow, &c->occ_shaft, &c->occ_shade);
     // k_trace uses static tile striding: with more than ~4 blocks/CU a wave owns so few tiles (32,400 tiles at 1080p)
     // that heavy object tiles no longer average out (measured 0.26 ms at 4 blocks/CU vs 0.38 ms at 7-8)
     if (c->occ_trace_primary > 4) c->occ_trace_primary = 4;
     if (c->occ_trace_rays > 4) c->occ_trace_rays = 4;
-    c->occ_trace_primary *= c->grid_mult; c->occ_trace_rays *= c->grid_mult; c->occ_shadow *= c->grid_mult; c->occ_shade *= c->grid_mult;
+    c->occ_trace_primary *= c->grid_mult; c->occ_trace_rays *= c->grid_mult; c->occ_shadow *= c->grid_mult; c->occ_shaft *= c->grid_mult; c->occ_shade *= c->grid_mult;
     c->has_scene = true;
     return RT_OK;
 }
@@ -702,13 +702,13 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
         // tree scenes with one (hit, light) pair per wave: the shaft walk (rt_kernels.hip, k_shadow_shaft)
         const bool shaft = !c->flat && !count && c->S.shaft != 0 && L.n_samples >= c->shaft_min_samples;
         if (shaft)
-            launch_shadow_shaft(c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis,
+            launch_shadow_shaft(c->cus * c->occ_shaft, st, c->S, L, level, 3 * level + 1, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis,
                                 c->d_tasks[0], c->task_cap, c->shaft_budget, c->task_target, sidx);
         else
             launch_shadow(count, c->flat, c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis,
                           c->d_tasks[0], c->task_cap, c->shadow_budget, c->task_target, sidx);
         if (shaft && c->shaft_budget != 0u)
-            launch_shadow_shaft_cont(c->cus * c->occ_shadow, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[0], c->task_cap, sidx);
+            launch_shadow_shaft_cont(c->cus * c->occ_shaft, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[0], c->task_cap, sidx);
         else if (!shaft && !c->flat && !count && c->shadow_budget != 0u)      // the big leaves of the shadow units, spread over all waves
             launch_shadow_cont(c->cus * c->occ_shadow, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[0], nullptr, 2u, 0u,
                                c->task_cap, 0u, sidx);

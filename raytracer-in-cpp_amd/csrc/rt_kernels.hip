@@ -455,8 +455,6 @@ __device__ __forceinline__ void leaf_visit(const DNode &nd, const uint32_t ni, c
         for (uint32_t c0 = cb * 64u; c0 < t_end; c0 += 64u) {
             const uint32_t n = cnt - c0 < 64u ? cnt - c0 : 64u;
             const bool has = static_cast<uint32_t>(lane) < n && !(ANY && (tr.flags & 1u));
-            const uint32_t nx = c0 + 64u + static_cast<uint32_t>(lane);
-            const TriRec nxt = T[nx < cnt ? nx : 0u];                      // prefetch (uniformly skipped work is cheap)
             // conservative chunk test (lanes = rays): a live ray skips the chunk when no point of its line that a hit could
             // count at lies in the chunk's inflated box (rt_capi.cpp, build_chunk_bounds, has the error analysis)
             unsigned long long todo = live;
@@ -586,7 +584,7 @@ __device__ __forceinline__ void leaf_visit(const DNode &nd, const uint32_t ni, c
                 }
             }
             if (ANY && !COUNT && live == 0ull) break;
-            tr = nxt;
+            { const uint32_t nx = c0 + 64u + static_cast<uint32_t>(lane); if (c0 + 64u < t_end) tr = T[nx < cnt ? nx : 0u]; }
         }
         if (ANY) occluded = occluded || (((occ_new >> lane) & 1ull) != 0ull);
     } else {
@@ -3074,7 +3072,7 @@ void launch_set_prof(hipStream_t, Control *, uint32_t) {}
 // ------------------------------------------------------------------------------------------------------
 // residency: blocks per CU for each persistent kernel (fast variants), queried once per scene
 // ------------------------------------------------------------------------------------------------------
-void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow, int *shade) {
+void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow, int *shaft_out, int *shade) {
     int n = 0;
     auto q = [&](auto kernel, int threads, int fallback) {
         return (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) == hipSuccess && n > 0) ? n : fallback;
@@ -3083,12 +3081,12 @@ void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow
         *trace_primary = q(k_trace<true, false, true>, RT_WAVES * 64, 4);
         *trace_rays = q(k_trace<false, false, true>, RT_WAVES * 64, 4);
         *shadow = q(k_shadow<false, true, false>, RT_WAVES * 64, 4);
+        *shaft_out = *shadow;
     } else {
         *trace_primary = q(k_stage<true, false, 0, false>, RT_WAVES * 64, 4);
         *trace_rays = q(k_stage<false, false, 0, false>, RT_WAVES * 64, 4);
         *shadow = q(k_shadow<false, false, false>, RT_WAVES * 64, 4);
-        const int shaft = q((k_shadow_shaft<false, false>), RT_WAVES * 64, 4);
-        if (shaft < *shadow) *shadow = shaft;
+        *shaft_out = q((k_shadow_shaft<false, false>), RT_WAVES * 64, 4);      // (its grid used to be the smaller of the two residencies: 4 of its 6 waves per SIMD)
     }
     *shade = q(k_shade, 256, 2);
 }
