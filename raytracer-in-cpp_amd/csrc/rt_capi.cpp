@@ -84,6 +84,7 @@ struct rt_ctx {
     bool beam_trees = false;
     int shaft_min_samples = 33;           // tree scenes: sample counts from which a (hit, light) pair gets a wave of its own (k_shadow_shaft)
     uint32_t shaft_budget = 0u;           // the shaft walk culls per triangle: its leaves are cheap enough to stay inline (dodge 1080p: 1.31 -> 1.22 ms without tasks)
+    uint32_t shaft_budget_deep = 3000u;   // ... but the bounce levels have few units and a heavy tail: their big leaves do go to a leaf-task launch (cfg4 29.2 -> 28.3 ms)
     int stage_mult = 2;                         // grid multiplier of the main k_stage launches (RT_STAGE_MULT): twice the resident grid lets
                                                 // blocks of sky tiles retire early and evens out the object tiles (dodge trace 0.278 -> 0.254 ms)
     uint32_t task_target = 0u;                  // estimated cost of one leaf-task piece (0 = same as the budget)
@@ -145,7 +146,7 @@ extern "C" rt_status rt_create(rt_ctx **out, int device) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *dt = std::getenv("RT_TRACE_DYNAMIC")) c->dyn_trace = std::atoi(dt) != 0;
     if (const char *sb = std::getenv("RT_SHADOW_BUDGET")) c->shadow_budget = static_cast<uint32_t>(std::atoi(sb));
-    if (const char *sb = std::getenv("RT_SHAFT_BUDGET")) c->shaft_budget = static_cast<uint32_t>(std::atoi(sb));
+    if (const char *sb = std::getenv("RT_SHAFT_BUDGET")) c->shaft_budget = c->shaft_budget_deep = static_cast<uint32_t>(std::atoi(sb));
     if (const char *sm = std::getenv("RT_SHAFT_MIN_SAMPLES")) c->shaft_min_samples = std::atoi(sm);
     if (const char *bt = std::getenv("RT_BEAM_TREES")) c->beam_trees = std::atoi(bt) != 0;
     if (const char *sg = std::getenv("RT_STAGED_TRACE")) c->staged_trace = std::atoi(sg) != 0;
@@ -515,7 +516,7 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     c->S.queue_local = -1;        // auto (rt_kernels.hip, k_shadow); RT_QUEUE_LOCAL=n forces chunks of n consecutive units, 0 the strided mode
     if (const char *ql = std::getenv("RT_QUEUE_LOCAL")) c->S.queue_local = std::atoi(ql);
     c->S.plane_cull = (no_cull || std::getenv("RT_NO_PLANE_CULL") != nullptr) ? 0 : 1;
-    c->S.queue_div = 6;
+    c->S.queue_div = 12;          // (units / (waves x 12) per chunk: dodge 1.125 -> 1.112 ms against 6, measured at the kernel's full residency)
     if (const char *qd = std::getenv("RT_QUEUE_DIV")) { const int v = std::atoi(qd); if (v >= 1 && v <= 4096) c->S.queue_div = v; }
     c->S.shaft = (no_cull || std::getenv("RT_NO_SHAFT") != nullptr) ? 0 : 1;
     c->S.beam = (no_cull || std::getenv("RT_NO_BEAM") != nullptr) ? 0 : 1;
@@ -701,13 +702,14 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
         if (beam) launch_beam(c->cus * 4, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_sidx);
         // tree scenes with one (hit, light) pair per wave: the shaft walk (rt_kernels.hip, k_shadow_shaft)
         const bool shaft = !c->flat && !count && c->S.shaft != 0 && L.n_samples >= c->shaft_min_samples;
+        const uint32_t shaft_b = level == 0 ? c->shaft_budget : c->shaft_budget_deep;
         if (shaft)
             launch_shadow_shaft(c->cus * c->occ_shaft, st, c->S, L, level, 3 * level + 1, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis,
-                                c->d_tasks[0], c->task_cap, c->shaft_budget, c->task_target, sidx);
+                                c->d_tasks[0], c->task_cap, shaft_b, c->task_target, sidx);
         else
             launch_shadow(count, c->flat, c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis,
                           c->d_tasks[0], c->task_cap, c->shadow_budget, c->task_target, sidx);
-        if (shaft && c->shaft_budget != 0u)
+        if (shaft && shaft_b != 0u)
             launch_shadow_shaft_cont(c->cus * c->occ_shaft, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[0], c->task_cap, sidx);
         else if (!shaft && !c->flat && !count && c->shadow_budget != 0u)      // the big leaves of the shadow units, spread over all waves
             launch_shadow_cont(c->cus * c->occ_shadow, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[0], nullptr, 2u, 0u,
