@@ -2701,26 +2701,44 @@ __device__ const unsigned long long POWF_EXP2_TAB[32] = {
     0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
     0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
 
-__device__ __forceinline__ float pow_shininess(const float x, const float y) {
-    uint32_t ix = __float_as_uint(x);
+// The tables live in LDS for the kernel (64 x 8 B: INVC[16] | LOGC[16] | EXP2_TAB[32]): a lookup is a ds_read_b64, not a global load on the
+// critical path of every sample.  The function has NO divergent branch: the one common special case (cosphi = +0 with a positive finite
+// shininess: the answer is +0) and the three range answers of the main path are selects; everything else e_powf.c answers without
+// arithmetic (NaN, inf, subnormal x, y = 0 / inf / NaN, negative y at x = 0) sits behind ONE wave-uniform test and is resolved with selects
+// there.  (The straight translation -- nine early returns -- cost k_shade ~40 exec-mask branches and three dependent global loads per two
+// samples: cube k_shade 0.236 ms.)
+__device__ __forceinline__ float pow_shininess(const float x, const float y, const double *__restrict__ tab) {
+    const uint32_t ix0 = __float_as_uint(x);
     const uint32_t iy = __float_as_uint(y);
     const bool y_special = (2u * iy - 1u) >= (2u * 0x7f800000u - 1u);                 // y is 0, inf or NaN
-    if (!(ix - 0x00800000u < 0x7f800000u - 0x00800000u) || y_special) {
-        // the cases e_powf.c answers without arithmetic (x >= 0 here: cosphi = max(0, .)), then subnormal x
-        if (2u * iy == 0u) return 1.0f;                                                // pow(x, +-0) = 1
-        if (x == 1.0f) return 1.0f;
-        if (x != x || y != y) return x + y;                                            // NaN
-        if (2u * iy == 2u * 0x7f800000u) {                                             // y = +-inf
-            const bool small = 2u * ix < 2u * 0x3f800000u;                            // |x| < 1
-            return (small == ((iy >> 31) != 0u)) ? __uint_as_float(0x7f800000u) : 0.0f;
-        }
-        if (2u * ix == 0u) return (iy >> 31) ? __uint_as_float(0x7f800000u) : 0.0f;    // pow(+0, y): 0 for y > 0, +inf for y < 0
-        if (ix == 0x7f800000u) return (iy >> 31) ? 0.0f : x;                           // pow(+inf, y)
-        if (ix >> 31) return __uint_as_float(0x7fc00000u);                             // negative x: not reachable from phongShade
+    const bool special = !(ix0 - 0x00800000u < 0x7f800000u - 0x00800000u) || y_special;
+    const bool zero_common = (ix0 == 0u) && !y_special && (iy >> 31) == 0u;            // pow(+0, y), y > 0 finite: +0
+    uint32_t ix = zero_common ? 0x3f800000u : ix0;
+    bool use_spec = false;
+    float spec = 0.0f;
+    if (__ballot(special && !zero_common) != 0ull) {
+        // e_powf.c's cases without arithmetic, first match wins (x >= 0 or NaN here: cosphi = max(0, .)), then subnormal x
+        const bool odd = special && !zero_common;
+        const bool c1 = 2u * iy == 0u;                                                  // pow(x, +-0) = 1
+        const bool c2 = x == 1.0f;
+        const bool c3 = (x != x) || (y != y);                                           // NaN
+        const bool c4 = 2u * iy == 2u * 0x7f800000u;                                    // y = +-inf
+        const bool c5 = 2u * ix0 == 0u;                                                 // pow(+-0, y)
+        const bool c6 = ix0 == 0x7f800000u;                                             // pow(+inf, y)
+        const bool c7 = (ix0 >> 31) != 0u;                                              // negative x: not reachable from phongShade
+        const bool yneg = (iy >> 31) != 0u;
+        const bool small = 2u * ix0 < 2u * 0x3f800000u;                                // |x| < 1
+        const float inf = __uint_as_float(0x7f800000u);
+        const float v4 = (small == yneg) ? inf : 0.0f;
+        const float v5 = yneg ? inf : 0.0f;
+        const float v6 = yneg ? 0.0f : x;
+        spec = c1 ? 1.0f : (c2 ? 1.0f : (c3 ? x + y : (c4 ? v4 : (c5 ? v5 : (c6 ? v6 : __uint_as_float(0x7fc00000u))))));
+        use_spec = odd && (c1 || c2 || c3 || c4 || c5 || c6 || c7);
         // subnormal x: normalise as e_powf.c does
-        ix = __float_as_uint(x * 0x1p23f);
-        ix &= 0x7fffffffu;
-        ix -= 23u << 23;
+        uint32_t isub = __float_as_uint(x * 0x1p23f);
+        isub &= 0x7fffffffu;
+        isub -= 23u << 23;
+        ix = use_spec ? 0x3f800000u : ((odd && !use_spec) ? isub : ix);
     }
     // log2_inline
     const uint32_t tmp = ix - 0x3f330000u;
@@ -2728,8 +2746,8 @@ __device__ __forceinline__ float pow_shininess(const float x, const float y) {
     const uint32_t top = tmp & 0xff800000u;
     const int k = static_cast<int>(top) >> 23;
     const double z = static_cast<double>(__uint_as_float(ix - top));
-    const double r = __builtin_fma(z, POWF_LOG2_INVC[i], -1.0);
-    const double y0 = POWF_LOG2_LOGC[i] + static_cast<double>(k);
+    const double r = __builtin_fma(z, tab[i], -1.0);
+    const double y0 = tab[16u + i] + static_cast<double>(k);
     const double r2 = r * r;
     const double yy = __builtin_fma(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
     const double p = __builtin_fma(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
@@ -2738,24 +2756,27 @@ __device__ __forceinline__ float pow_shininess(const float x, const float y) {
     q = __builtin_fma(p, r2, q);
     const double logx = __builtin_fma(yy, r4, q);
     const double ylogx = static_cast<double>(y) * logx;
-    if (((static_cast<unsigned long long>(__double_as_longlong(ylogx)) >> 47) & 0xffffull) >= 0x80bfull) {       // |y * log2(x)| >= 126
-        if (ylogx > 0x1.fffffffd1d571p+6) return __uint_as_float(0x7f800000u);       // __math_oflowf
-        if (ylogx <= -150.0) return 0.0f;                                              // __math_uflowf
-        if (ylogx < -149.0) return __uint_as_float(1u);                                // __math_may_uflowf: the smallest subnormal
-    }
+    // |y * log2(x)| >= 126: __math_oflowf / __math_uflowf / __math_may_uflowf, else the ordinary path (also for -149 <= y log2 x <= -126)
+    const bool big = ((static_cast<unsigned long long>(__double_as_longlong(ylogx)) >> 47) & 0xffffull) >= 0x80bfull;
+    const bool r_of = big && (ylogx > 0x1.fffffffd1d571p+6);
+    const bool r_uf = big && !r_of && (ylogx <= -150.0);
+    const bool r_mu = big && !r_of && !r_uf && (ylogx < -149.0);
     // exp2_inline
     double kd = ylogx + 0x1.8p+47;
     const unsigned long long ki = static_cast<unsigned long long>(__double_as_longlong(kd));
     kd -= 0x1.8p+47;
     const double rr = ylogx - kd;
-    const unsigned long long t = POWF_EXP2_TAB[ki & 31ull] + (ki << 47);
+    const unsigned long long t = static_cast<unsigned long long>(__double_as_longlong(tab[32u + static_cast<uint32_t>(ki & 31ull)])) + (ki << 47);
     const double sc = __longlong_as_double(static_cast<long long>(t));
     const double zz = __builtin_fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
     const double rr2 = rr * rr;
     double yv = __builtin_fma(0x1.62e42ff0c52d6p-1, rr, 1.0);
     yv = __builtin_fma(zz, rr2, yv);
     yv = yv * sc;
-    return static_cast<float>(yv);
+    float res = static_cast<float>(yv);
+    res = r_of ? __uint_as_float(0x7f800000u) : (r_uf ? 0.0f : (r_mu ? __uint_as_float(1u) : res));
+    res = use_spec ? spec : res;
+    return zero_common ? 0.0f : res;
 }
 
 __device__ __forceinline__ float fresnel_term(float ix, float iy, float iz, float nx, float ny, float nz, float ior) {
@@ -2780,6 +2801,12 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
                                                const int lslots, const ShadeItem *__restrict__ items, Control *__restrict__ ctl,
                                                const unsigned long long *__restrict__ vis, float4 *__restrict__ rec,
                                                float *__restrict__ fres, RayItem *__restrict__ rays_out) {
+    __shared__ double s_pow[64];               // powf tables: INVC[16] | LOGC[16] | EXP2_TAB[32] (bit patterns)
+    if (threadIdx.x < 64u) {
+        const uint32_t ti = threadIdx.x;
+        s_pow[ti] = ti < 16u ? POWF_LOG2_INVC[ti] : (ti < 32u ? POWF_LOG2_LOGC[ti - 16u] : __longlong_as_double(static_cast<long long>(POWF_EXP2_TAB[ti - 32u])));
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const ShardMap imap = shard_map(ctl->n_items[level], lane, F.item_cap, 1u, 64u);      // groups of 64 items, shard after shard
     const uint32_t ntiles = imap.total;
@@ -2873,7 +2900,7 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
                     float rx = ldx - two * nx, ry = ldy - two * ny, rz = ldz - two * nz;
                     normalize3(rx, ry, rz);
                     const float cosphi = smax(0.0f, dot3(ex, ey, ez, -1.0f * rx, -1.0f * ry, -1.0f * rz));
-                    const float pw = pow_shininess(cosphi, mat.shininess);
+                    const float pw = pow_shininess(cosphi, mat.shininess, s_pow);
                     const float tr_ = lkd0 * costheta + lks0 * pw, tg_ = lkd1 * costheta + lks1 * pw, tb_ = lkd2 * costheta + lks2 * pw;
                     cr = cr + (visible ? tr_ : 0.0f);
                     cg = cg + (visible ? tg_ : 0.0f);
