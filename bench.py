@@ -63,7 +63,7 @@ COST = {
     "unit_flat": 355,            # flat k_shadow per unit: queue, item, h, shaft planes (~85), 8 triangles x 8 tests per step (2 x ~45 on the cube), plane rule, visibility word
     "unit_stack": 200,
     "beam": 700,                 # k_beam per (tile of 64 hits, light) on a flat scene: items, wave min / max, planes, one leaf (chunk test + per-triangle test)
-    "shade_sample": 187,         # k_shade per (tile of 64 hits, sample): light direction + reflection normalised (2 x sqrt + 6 IEEE divisions), glibc powf in double
+    "shade_sample": 215,         # k_shade per (tile of 64 hits, sample): light direction + reflection normalised (2 x sqrt + 6 IEEE divisions), glibc powf in double (branch-free: range and special answers are selects)
     "shade_tile": 500,           # k_shade per tile: items, interpolated normal, eye vector, material, record
 }
 
