@@ -2168,7 +2168,11 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
     const LightGrid lg0 = light_grid(L, L.pos[0][0], L.pos[0][1], L.pos[0][2]);
     const uint32_t bpr = blocks ? (vst >> 3) : 1u;
     const float inv_P = 1.0f / static_cast<float>(P), inv_bpr = 1.0f / static_cast<float>(bpr), inv_ls = 1.0f / static_cast<float>(lslots);
-    auto udiv = [](const uint32_t n, const uint32_t d, const float inv) -> uint32_t {
+    // (a power-of-two divisor -- 256 samples: 4 passes, 2 blocks per row -- is a shift)
+    const int sh_P = (P & (P - 1u)) == 0u ? __builtin_ctz(P) : -1, sh_bpr = (bpr & (bpr - 1u)) == 0u ? __builtin_ctz(bpr) : -1;
+    const int sh_ls = (static_cast<uint32_t>(lslots) & (static_cast<uint32_t>(lslots) - 1u)) == 0u ? __builtin_ctz(static_cast<uint32_t>(lslots)) : -1;
+    auto udiv = [](const uint32_t n, const uint32_t d, const float inv, const int sh) -> uint32_t {
+        if (sh >= 0) return n >> sh;
         uint32_t qv = static_cast<uint32_t>(static_cast<float>(n) * inv);          // within +-2 of n / d for n < 2^31
         if (qv * d > n) qv -= 1u;
         if (qv * d > n) qv -= 1u;
@@ -2213,8 +2217,8 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         }
         uint32_t sh, lu, n_sh;
         shard_find(imap, unit, sh, lu, n_sh);
-        const uint32_t g = P == 1u ? lu : udiv(lu, P, inv_P), pass = lu - g * P;                       // (hit, light) pair of the list shard, pass of it
-        const uint32_t item_i = lslots == 1 ? g : udiv(g, static_cast<uint32_t>(lslots), inv_ls);
+        const uint32_t g = P == 1u ? lu : udiv(lu, P, inv_P, sh_P), pass = lu - g * P;                       // (hit, light) pair of the list shard, pass of it
+        const uint32_t item_i = lslots == 1 ? g : udiv(g, static_cast<uint32_t>(lslots), inv_ls, sh_ls);
         const int l = static_cast<int>(g - item_i * static_cast<uint32_t>(lslots));
         uint32_t item_at = uniform_u32(sh * item_cap + item_i);
         if (sidx != nullptr) item_at = uniform_u32(sidx[item_at]);            // k_beam's survivors: position in the list -> item storage index
@@ -2223,7 +2227,7 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         float fi = fi_lane + 0.5f, fj = fj_lane + 0.5f;                       // the lane's sample (i + 0.5, j + 0.5) -- P == 1: s = lane
         float b_i0 = 0.5f, b_j0 = 0.5f, b_i1 = fi_last, b_j1 = fj_last;      // grid corners of the unit's samples (the whole light unless in blocks)
         if (blocks) {
-            const uint32_t bi = udiv(pass, bpr, inv_bpr), bj = pass - bi * bpr;
+            const uint32_t bi = udiv(pass, bpr, inv_bpr, sh_bpr), bj = pass - bi * bpr;
             s = (bi * 8u + (static_cast<uint32_t>(lane) >> 3)) * vst + bj * 8u + (static_cast<uint32_t>(lane) & 7u);
             b_i0 = static_cast<float>(bi * 8u) + 0.5f; b_j0 = static_cast<float>(bj * 8u) + 0.5f;
             b_i1 = static_cast<float>(bi * 8u + 7u) + 0.5f; b_j1 = static_cast<float>(bj * 8u + 7u) + 0.5f;
