@@ -143,21 +143,41 @@ bool HostScene::load_ply(const std::string &path, std::string *err) {
             else if (f != "binary_little_endian") { if (err) *err = "unsupported PLY format " + f; return false; }
             have_format = true;
         } else if (key == "element") {
-            PlyElem e; ls >> e.name >> e.count; elems.push_back(e);
+            PlyElem e;
+            long long cnt = -1;
+            if (!(ls >> e.name >> cnt) || cnt < 0) { if (err) *err = "bad PLY element line: " + line; return false; }
+            e.count = static_cast<size_t>(cnt);
+            elems.push_back(e);
         } else if (key == "property" && !elems.empty()) {
             PlyProp p; std::string t; ls >> t;
             if (t == "list") {
-                std::string ct, it; ls >> ct >> it >> p.name;
+                std::string ct, it;
+                if (!(ls >> ct >> it >> p.name)) { if (err) *err = "bad PLY property line: " + line; return false; }
                 p.list = true;
                 if (!ply_type(ct, &p.count_size, &p.count_kind) || !ply_type(it, &p.size, &p.kind)) { if (err) *err = "bad PLY list type"; return false; }
             } else {
-                ls >> p.name;
+                if (!(ls >> p.name)) { if (err) *err = "bad PLY property line: " + line; return false; }
                 if (!ply_type(t, &p.size, &p.kind)) { if (err) *err = "bad PLY type " + t; return false; }
             }
             elems.back().props.push_back(p);
         }
     }
     if (!have_format) { if (err) *err = "PLY header without a format line"; return false; }
+    // The file is not trusted: every element count is bounded by what the rest of the file can hold (a record takes at least one byte per
+    // property -- binary: the scalar sizes, a list its count field; ascii: at least one digit -- and an element without properties
+    // takes none, so it may not claim records at all).
+    const std::streamoff body0 = in.tellg();
+    in.seekg(0, std::ios::end);
+    const std::streamoff file_end = in.tellg();
+    in.seekg(body0, std::ios::beg);
+    if (body0 < 0 || file_end < body0) { if (err) *err = "cannot size " + path; return false; }
+    unsigned long long budget = static_cast<unsigned long long>(file_end - body0);
+    for (const PlyElem &e : elems) {
+        unsigned long long rec = 0;
+        for (const PlyProp &p : e.props) rec += ascii ? 1ull : static_cast<unsigned long long>(p.list ? p.count_size : p.size);
+        if (e.count != 0 && (rec == 0 || e.count > budget / rec)) { if (err) *err = "PLY element '" + e.name + "' claims more records than the file holds"; return false; }
+        budget -= rec * e.count;
+    }
     verts.clear(); normals.clear(); tris.clear(); mats.clear();
     std::vector<MeshGroup> groups(1);
     for (const PlyElem &e : elems) {
@@ -168,10 +188,16 @@ bool HostScene::load_ply(const std::string &path, std::string *err) {
                 if (p.list) {
                     double cnt = 0;
                     if (!ply_scalar(in, ascii, p.count_size, p.count_kind, &cnt)) { if (err) *err = "truncated PLY"; return false; }
+                    // (a list longer than the rest of the file is refused before the loop runs; NaN compares false)
+                    if (!(cnt >= 0.0 && cnt <= static_cast<double>(file_end - body0))) { if (err) *err = "bad PLY list length"; return false; }
                     for (long k = 0; k < static_cast<long>(cnt); ++k) {
                         double val = 0;
                         if (!ply_scalar(in, ascii, p.size, p.kind, &val)) { if (err) *err = "truncated PLY"; return false; }
-                        if (e.name == "face" && p.name == "vertex_indices" && k < 3) groups[0].ids.push_back(static_cast<uint32_t>(val));   // face_cb: value_index 0..2
+                        if (e.name == "face" && p.name == "vertex_indices" && k < 3) {     // face_cb: value_index 0..2
+                            // the cast of a negative, non-finite or >= 2^32 double to uint32_t is undefined: refuse it here
+                            if (!(val >= 0.0 && val < 4294967296.0)) { if (err) *err = "PLY face index out of range"; return false; }
+                            groups[0].ids.push_back(static_cast<uint32_t>(val));
+                        }
                     }
                 } else {
                     double val = 0;

@@ -97,8 +97,9 @@ struct rt_ctx {
     uint64_t frame_generation = 0;    // bumped whenever the frame buffers are reallocated (invalidates captured graphs)
     uint64_t scene_generation = 0;    // bumped by every rt_upload_scene: a captured graph holds the scene's device pointers by value
     hipEvent_t cam_events[512] = {};  // one per camera-ring slot: recorded after the slot's H2D copy, waited for before the slot is reused
-    float *d_offsets = nullptr;  // RT_LIGHT_SPHERE sample offsets of the last call
+    float *d_offsets = nullptr;  // RT_LIGHT_SPHERE sample offsets of the last eager call (a captured graph owns a copy of its own: rt_graph)
     size_t cap_offsets = 0;
+    hipStream_t last_frame_stream = nullptr;   // stream of the most recent eager frame (it may still read d_offsets)
     float *d_rgb = nullptr;      // staging for rt_render (host output)
     int32_t *d_hit = nullptr;
     float *d_t = nullptr;
@@ -540,7 +541,9 @@ extern "C" int32_t rt_local_rows(const rt_params *p) {
     return n;
 }
 
-static rt_status check_lights(rt_ctx *c, const rt_lights *l, DLights *out) {
+// `own_offsets` (rt_graph_create): the sphere offsets go to a NEW device buffer handed to the caller instead of the context's buffer --
+// a captured graph holds the pointer by value, so it must not be the buffer later calls rewrite or reallocate.
+static rt_status check_lights(rt_ctx *c, const rt_lights *l, DLights *out, float **own_offsets = nullptr) {
     if (!l || l->n_lights < 1 || l->n_lights > RT_MAX_LIGHTS) { c->err = "lights: n_lights must be in 1..25 (the reference overflows bool[25] beyond)"; return RT_ERR_INVALID; }
     if (l->mode != RT_LIGHT_POINT && l->mode != RT_LIGHT_AREA && l->mode != RT_LIGHT_SPHERE) { c->err = "lights: mode must be point, area or sphere"; return RT_ERR_INVALID; }
     int ns = 1;
@@ -561,18 +564,27 @@ static rt_status check_lights(rt_ctx *c, const rt_lights *l, DLights *out) {
     out->n_samples = ns; out->len_x = l->len_x; out->len_y = l->len_y;
     out->offsets = nullptr;
     if (l->mode == RT_LIGHT_SPHERE) {
-        // the offsets travel to a context-owned device buffer (synchronous copy: sphere mode is not a latency path); their box bounds the samples
+        // the offsets travel to a device buffer (synchronous copy: sphere mode is not a latency path); their box bounds the samples
         const size_t bytes = static_cast<size_t>(ns) * 3 * sizeof(float);
-        if (bytes > c->cap_offsets) {
+        if (own_offsets) {
+            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(own_offsets), bytes));
+            HIPCHK(c, hipMemcpy(*own_offsets, l->offsets, bytes, hipMemcpyHostToDevice));
+            out->offsets = *own_offsets;
+        } else {
+            // a frame in flight -- on the context's stream or on the caller's stream of the last eager frame -- may still read the buffer
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            if (c->d_offsets) (void)hipFree(c->d_offsets);
-            c->d_offsets = nullptr; c->cap_offsets = 0;
-            HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_offsets), bytes));
-            c->cap_offsets = bytes;
+            // (a caller's stream that has been destroyed since has no work left: its error is not ours)
+            if (c->last_frame_stream && c->last_frame_stream != c->stream && hipStreamSynchronize(c->last_frame_stream) != hipSuccess) (void)hipGetLastError();
+            c->last_frame_stream = nullptr;
+            if (bytes > c->cap_offsets) {
+                if (c->d_offsets) (void)hipFree(c->d_offsets);
+                c->d_offsets = nullptr; c->cap_offsets = 0;
+                HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_offsets), bytes));
+                c->cap_offsets = bytes;
+            }
+            HIPCHK(c, hipMemcpy(c->d_offsets, l->offsets, bytes, hipMemcpyHostToDevice));
+            out->offsets = c->d_offsets;
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream));          // a frame in flight may still read the previous offsets
-        HIPCHK(c, hipMemcpy(c->d_offsets, l->offsets, bytes, hipMemcpyHostToDevice));
-        out->offsets = c->d_offsets;
         for (int k = 0; k < 3; ++k) { out->obox[k] = l->offsets[k]; out->obox[3 + k] = l->offsets[k]; }
         for (int i = 1; i < ns; ++i)
             for (int k = 0; k < 3; ++k) {
@@ -870,6 +882,7 @@ extern "C" rt_status rt_render_device(rt_ctx *c, const rt_camera *cam, const rt_
     DCam dc;
     make_cam(cam, &dc);
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    c->last_frame_stream = st;
     const int levels_run = c->reflective ? F.max_depth + 1 : 1;
     if (stats && p->collect_stats == 1) {
         // counting pass: same frame with the no-early-out traversal variants (never part of a timed region)
@@ -901,6 +914,7 @@ struct rt_graph {
     DFrame F{};
     uint64_t generation = 0, scene_generation = 0;
     hipStream_t last_stream = nullptr;
+    float *d_offsets = nullptr;       // RT_LIGHT_SPHERE: the graph's own copy of the sample offsets (the kernel arguments hold this pointer)
 };
 
 extern "C" rt_status rt_graph_create(rt_ctx *c, const rt_lights *lights, const rt_params *p, float *d_out_rgb, uint8_t *d_out_u8,
@@ -911,28 +925,32 @@ extern "C" rt_status rt_graph_create(rt_ctx *c, const rt_lights *lights, const r
     if (!d_out_rgb && !d_out_u8) { c->err = "rt_graph_create: no output buffer"; return RT_ERR_INVALID; }
     HIPCHK(c, hipSetDevice(c->device));
     DLights L;
-    rt_status s = check_lights(c, lights, &L);
-    if (s != RT_OK) return s;
+    float *own_offsets = nullptr;
+    rt_status s = check_lights(c, lights, &L, &own_offsets);
+    if (s != RT_OK) { if (own_offsets) (void)hipFree(own_offsets); return s; }
     DFrame F;
-    if ((s = make_frame(c, p, &F)) != RT_OK) return s;
-    if (F.npix == 0) { c->err = "rt_graph_create: empty shard"; return RT_ERR_INVALID; }
+    if ((s = make_frame(c, p, &F)) != RT_OK) { if (own_offsets) (void)hipFree(own_offsets); return s; }
+    if (F.npix == 0) { if (own_offsets) (void)hipFree(own_offsets); c->err = "rt_graph_create: empty shard"; return RT_ERR_INVALID; }
     // every allocation happens BEFORE the capture
     const size_t P = (static_cast<size_t>(L.n_samples) + 63) / 64;
-    if ((s = ensure_frame(c, F.npix, F.max_depth + 1, P, frame_tiles(F), static_cast<size_t>(L.n_lights))) != RT_OK) return s;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((s = ensure_frame(c, F.npix, F.max_depth + 1, P, frame_tiles(F), static_cast<size_t>(L.n_lights))) != RT_OK) { if (own_offsets) (void)hipFree(own_offsets); return s; }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { if (own_offsets) (void)hipFree(own_offsets); c->err = "rt_graph_create: hipStreamSynchronize failed"; return RT_ERR_HIP; }
     rt_graph *g = new rt_graph();
+    g->d_offsets = own_offsets;
     g->ctx = c; g->F = F; g->generation = c->frame_generation; g->scene_generation = c->scene_generation;
-    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { delete g; c->err = "hipStreamBeginCapture failed"; return RT_ERR_HIP; }
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { if (g->d_offsets) (void)hipFree(g->d_offsets); delete g; c->err = "hipStreamBeginCapture failed"; return RT_ERR_HIP; }
     s = run_frame(c, c->stream, nullptr, L, F, true, false, d_out_rgb, d_out_u8, nullptr, nullptr, 0, 0);
     const hipError_t e = hipStreamEndCapture(c->stream, &g->graph);
     if (s != RT_OK || e != hipSuccess || !g->graph) {
         if (g->graph) (void)hipGraphDestroy(g->graph);
+        if (g->d_offsets) (void)hipFree(g->d_offsets);
         delete g;
         if (s == RT_OK) { c->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); s = RT_ERR_HIP; }
         return s;
     }
     if (hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) {
         (void)hipGraphDestroy(g->graph);
+        if (g->d_offsets) (void)hipFree(g->d_offsets);
         delete g;
         c->err = "hipGraphInstantiate failed";
         return RT_ERR_HIP;
@@ -973,6 +991,7 @@ extern "C" void rt_graph_destroy(rt_graph *g) {
     if (g->last_stream) (void)hipStreamSynchronize(g->last_stream);
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
+    if (g->d_offsets) (void)hipFree(g->d_offsets);
     delete g;
 }
 

@@ -2173,11 +2173,13 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
     const int sh_ls = (static_cast<uint32_t>(lslots) & (static_cast<uint32_t>(lslots) - 1u)) == 0u ? __builtin_ctz(static_cast<uint32_t>(lslots)) : -1;
     auto udiv = [](const uint32_t n, const uint32_t d, const float inv, const int sh) -> uint32_t {
         if (sh >= 0) return n >> sh;
-        uint32_t qv = static_cast<uint32_t>(static_cast<float>(n) * inv);          // within +-2 of n / d for n < 2^31
-        if (qv * d > n) qv -= 1u;
+        // float(n) * inv is off by about q * 2^-23 (q = n / d): one correction step each way is exact while q < 2^23; beyond that
+        // (a per-shard unit count of a very large frame with many lights and a non-power-of-two pass count) the integer division
+        // itself decides -- never a wrong (item, light, pass)
+        uint32_t qv = static_cast<uint32_t>(static_cast<float>(n) * inv);
         if (qv * d > n) qv -= 1u;
         if (n - qv * d >= d) qv += 1u;
-        if (n - qv * d >= d) qv += 1u;
+        if (qv * d > n || n - qv * d >= d) qv = n / d;
         return qv;
     };
     const float fi_lane = blocks ? static_cast<float>(static_cast<uint32_t>(lane) >> 3) : static_cast<float>(static_cast<uint32_t>(lane) / vst);

@@ -1,0 +1,182 @@
+"""Round-3 parity additions.
+
+* The reference's own full-size `result.ppm` md5s (src/flyscene.cpp:641 writes the file) reproduced by the HIP path:
+  cube.obj 1000^2 point / area(25), cube.obj 1440^2 area(25), dodgeColorTest.obj 1440^2 area(25) -- the pixel-count twins of the headline
+  configuration at the reference's 25 samples.  The oracle reproduces the same seven md5s on the CPU (tests/test_oracle_golden.py).
+* bunny.ply (resources/models/bunny.ply, 69,451 faces, 361 nodes): the one deep-tree PLY the reference ships, through loader, device tree
+  build and a whole frame.
+* Light grids the earlier tests never rendered: usteps != vsteps, multi-pass grids that are not blocks of 8 x 8, pass / block-row / light-slot
+  counts that are not powers of two (k_shadow_shaft's float-reciprocal division, rt_kernels.hip: udiv).
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SCENES = os.path.join(HERE, "golden", "scenes")
+KA = json.load(open(os.path.join(HERE, "golden", "survey_known_answers.json")))
+
+
+def render_gpu(rt, ctx, cam, L, w, h, depth):
+    p = rt.make_params(w, h, depth)
+    rgb = np.zeros((h, w, 3), np.float32)
+    hits = np.zeros((h, w), np.int32)
+    st = ctx.lib.rt_render(ctx.handle, C.byref(cam), C.byref(L), C.byref(p), rgb.ctypes.data_as(C.c_void_p), hits.ctypes.data_as(C.c_void_p), None)
+    rt.capi.check(ctx.lib, ctx.handle, st, "rt_render")
+    return rgb, hits
+
+
+def assert_exact(rgb, hits, ref, rhits):
+    assert np.array_equal(hits, rhits), f"{int((hits != rhits).sum())} closest-hit face ids differ"
+    assert np.array_equal(rgb.view(np.uint32), ref.view(np.uint32)), f"max |RGB - oracle| = {float(np.abs(rgb - ref).max())}"
+    assert (rhits >= 0).sum() > 0.02 * rhits.size, "the frame must actually show the object"
+
+
+# ------------------------------------------------------------------------------------------ the reference's full-size md5s on the GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,size,area", [("cube.obj", 1000, 0), ("cube.obj", 1000, 1), ("cube.obj", 1440, 1), ("dodgeColorTest.obj", 1440, 1)])
+def test_reference_full_size_md5(rt, scene, size, area, tmp_path):
+    """raytraceScene(W, W) + writePPMImage at the reference's own settings (5 x 5 samples or the point light, natural depth): the bytes of
+    result.ppm hash to the value the unmodified reference produced."""
+    want = [c["md5"] for c in KA["result_ppm_md5"] if c["scene"] == scene and c["size"] == size and c["area"] == area]
+    assert len(want) == 1
+    hs = rt.HostScene(os.path.join(SCENES, scene), 1000, 15)
+    ctx = rt.Context(0)
+    ctx.upload(hs)
+    L = rt.make_lights(area=bool(area), usteps=5, vsteps=5)
+    rgb, hits = render_gpu(rt, ctx, rt.default_camera(size, size), L, size, size, -1)
+    out = tmp_path / "result.ppm"
+    assert ctx.lib.rt_write_ppm(str(out).encode(), rgb.ctypes.data_as(C.c_void_p), size, size) == 0
+    assert hashlib.md5(out.read_bytes()).hexdigest() == want[0]
+    ctx.close(); hs.close()
+
+
+# ------------------------------------------------------------------------------------------ bunny.ply
+def test_bunny_ply_host_scene_equals_oracle(rt, oracle):
+    """Product loader + host tree build vs the oracle's, array for array (69,451 faces -> 361 nodes / 288 leaves / 81,299 face refs)."""
+    path = os.path.join(SCENES, "bunny.ply")
+    hs = rt.HostScene(path, 1000, 15)
+    osc = oracle.load_scene(path)
+    a, oa = hs.arrays(), osc.arrays()
+    tri = oa["wverts"][oa["face_vid"].reshape(-1)].reshape(-1, 9)
+    assert np.array_equal(a["tri_verts"].view(np.uint32), tri.view(np.uint32))
+    assert np.array_equal(a["vert_normal"].view(np.uint32), oa["normals"].view(np.uint32))
+    assert np.array_equal(a["face_normal"].view(np.uint32), oa["face_normal"].view(np.uint32))
+    info = hs.info()
+    assert (info["nodes"], info["leaves"], info["face_refs"]) == (361, 288, 81299) and info["nodes"] == osc.nnodes
+    osc.close(); hs.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("u,depth", [(5, 2), (8, 2)])
+def test_bunny_ply_renders_like_the_oracle(rt, oracle, u, depth):
+    """A frame of the deep-tree PLY: 25 samples (two pairs per wave, stack walk) and 64 samples (shaft walk).  Parity unpinned beyond the
+    oracle: the reference's PLY importer never builds faces (plyimporter.hpp:186-262)."""
+    path = os.path.join(SCENES, "bunny.ply")
+    hs = rt.HostScene(path, 1000, 15)
+    ctx = rt.Context(0)
+    ctx.upload(hs)
+    osc = oracle.load_scene(path)
+    w, h = 240, 168
+    rgb, hits = render_gpu(rt, ctx, rt.default_camera(w, h), rt.make_lights(area=True, usteps=u, vsteps=u), w, h, depth)
+    ref, rhits, _ = osc.render(oracle.camera(w, h), oracle.lights(area=True, usteps=u, vsteps=u), w, h, max_depth=depth, threads=8, want_hits=True)
+    assert_exact(rgb, hits, ref, rhits)
+    osc.close(); ctx.close(); hs.close()
+
+
+@pytest.mark.gpu
+def test_bunny_ply_gpu_octree_build_equals_host_build(rt):
+    path = os.path.join(SCENES, "bunny.ply")
+    cpu = rt.HostScene(path, 1000, 15)
+    gpu = rt.HostScene(path, 1000, 15)
+    ctx = rt.Context(0)
+    gpu.build_gpu(ctx, 1000, 15)
+    a, b = cpu.arrays(), gpu.arrays()
+    assert cpu.info() == gpu.info() and cpu.info()["nodes"] == 361
+    assert np.array_equal(a["node_box"].view(np.uint32), b["node_box"].view(np.uint32))
+    for k in ("node_first", "node_count_flags", "face_refs"):
+        assert np.array_equal(a[k], b[k]), k
+    ctx.close(); cpu.close(); gpu.close()
+
+
+# ------------------------------------------------------------------------------------------ light grids
+GRIDS = [(12, 12), (24, 24), (8, 16), (16, 8), (5, 8), (9, 7)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["cube.obj", "dodgeColorTest.obj"])
+@pytest.mark.parametrize("us,vs", GRIDS)
+def test_light_grids_that_are_not_square_powers_of_two(rt, oracle, scene, us, vs):
+    """usteps x vsteps = 12 x 12 (P = 3 passes of 64, no blocks), 24 x 24 (blocks: 9 passes, 3 blocks per row), 8 x 16 / 16 x 8 (2 passes,
+    blocks, bpr 2 / 1: i and j must not be swapped), 5 x 8 and 9 x 7 (40 / 63 samples in one word; 9 x 7: two-pair packing does not apply).
+    Frame == oracle bit for bit."""
+    path = os.path.join(SCENES, scene)
+    hs = rt.HostScene(path, 1000, 15)
+    ctx = rt.Context(0)
+    ctx.upload(hs)
+    osc = oracle.load_scene(path)
+    w, h, depth = 176, 120, 2
+    rgb, hits = render_gpu(rt, ctx, rt.default_camera(w, h), rt.make_lights(area=True, usteps=us, vsteps=vs), w, h, depth)
+    ref, rhits, _ = osc.render(oracle.camera(w, h), oracle.lights(area=True, usteps=us, vsteps=vs), w, h, max_depth=depth, threads=8, want_hits=True)
+    assert_exact(rgb, hits, ref, rhits)
+    osc.close(); ctx.close(); hs.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,us,vs,beam_trees", [("cube.obj", 12, 12, False), ("dodgeColorTest.obj", 12, 12, False), ("dodgeColorTest.obj", 12, 12, True),
+                                                    ("dodgeColorTest.obj", 24, 24, False), ("dodgeColorTest.obj", 16, 8, True)])
+def test_three_lights_with_non_power_of_two_passes(rt, oracle, scene, us, vs, beam_trees, monkeypatch):
+    """Three lights (lslots = 3) at 12 x 12 (P = 3): both run-time divisions of a shaft unit go through the float-reciprocal path; 24 x 24
+    adds bpr = 3.  Once more with the beam test on the tree (RT_BEAM_TREES=1)."""
+    if beam_trees:
+        monkeypatch.setenv("RT_BEAM_TREES", "1")
+    pts = [(-1.0, 1.0, 1.0), (0.8, 0.4, 1.5), (0.0, 0.0, 2.0)]
+    path = os.path.join(SCENES, scene)
+    hs = rt.HostScene(path, 1000, 15)
+    ctx = rt.Context(0)
+    ctx.upload(hs)
+    osc = oracle.load_scene(path)
+    w, h, depth = 144, 96, 2
+    rgb, hits = render_gpu(rt, ctx, rt.default_camera(w, h), rt.make_lights(points=pts, area=True, usteps=us, vsteps=vs), w, h, depth)
+    ref, rhits, _ = osc.render(oracle.camera(w, h), oracle.lights(area=True, usteps=us, vsteps=vs, points=pts), w, h, max_depth=depth, threads=8, want_hits=True)
+    assert_exact(rgb, hits, ref, rhits)
+    osc.close(); ctx.close(); hs.close()
+
+
+# ------------------------------------------------------------------------------------------ captured graphs own their sphere offsets
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["cube.obj", "dodgeColorTest.obj"])
+def test_sphere_graph_survives_later_sphere_calls(rt, scene):
+    """A hipGraph captured in RT_LIGHT_SPHERE mode keeps rendering ITS offsets after later eager sphere-mode calls with different -- and
+    with more -- offsets (the context's buffer is rewritten, then reallocated: a graph that held that pointer would render other samples or
+    read freed memory)."""
+    path = os.path.join(SCENES, scene)
+    hs = rt.HostScene(path, 1000, 15)
+    ctx = rt.Context(0)
+    ctx.upload(hs)
+    w, h = 160, 96
+    cam = rt.default_camera(w, h)
+    p = rt.make_params(w, h, 2)
+    off_a = rt.sphere_offsets(65, 1.0, 64)
+    L_a = rt.set_sphere(rt.make_lights(area=False), off_a)
+    want, _ = render_gpu(rt, ctx, cam, L_a, w, h, 2)
+    out = rt.hipmem.DeviceBuffer(h * w * 3 * 4)
+    g = rt.FrameGraph(ctx, L_a, p, out.address, 0)
+    g.launch(cam); g.stats()
+    assert np.array_equal(out.to_numpy(np.float32, (h, w, 3)).view(np.uint32), want.view(np.uint32))
+    # same size, other offsets: the context's buffer is rewritten in place
+    L_b = rt.set_sphere(rt.make_lights(area=False), rt.sphere_offsets(7, 0.5, 64))
+    other, _ = render_gpu(rt, ctx, cam, L_b, w, h, 2)
+    assert not np.array_equal(other, want)
+    g.launch(cam); g.stats()
+    assert np.array_equal(out.to_numpy(np.float32, (h, w, 3)).view(np.uint32), want.view(np.uint32))
+    # more offsets: the context's buffer is reallocated
+    L_c = rt.set_sphere(rt.make_lights(area=False), rt.sphere_offsets(9, 1.0, 256))
+    render_gpu(rt, ctx, cam, L_c, w, h, 2)
+    g.launch(cam); g.stats()
+    assert np.array_equal(out.to_numpy(np.float32, (h, w, 3)).view(np.uint32), want.view(np.uint32))
+    g.close(); out.free(); ctx.close(); hs.close()

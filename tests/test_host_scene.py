@@ -216,3 +216,45 @@ def test_chunk_bounds_skip_triangles_the_reference_can_never_accept(rt, scenes):
     never = chunks - cullable
     assert chunks > 400 and 0 < never < 23, (chunks, cullable)         # 23 when every collinear triangle counted; the live ones sit in 22 chunks
     hs.close()
+
+
+def test_malformed_ply_files_are_refused(rt, tmp_path):
+    """The PLY loader does not trust the file (host_scene.cpp: load_ply): unparsable header lines, element counts the file cannot hold
+    (an element without properties may claim none), list lengths past the end of the file, and face indices that are negative,
+    non-finite or >= 2^32 (a cast that is undefined behaviour) all fail with RT_ERR_IO -- quickly, without allocating for the claim."""
+    import ctypes as C
+    import struct
+    import time
+    lib = rt.load_library()
+    h = C.c_void_p()
+    tri = "0 0 0\n1 0 0\n0 1 0\n"
+    head = "ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+    good = head + "element face 1\nproperty list uchar int vertex_indices\nend_header\n" + tri + "3 0 1 2\n"
+    cases = {
+        "ok.ply": (good, True),
+        "neg_index.ply": (good.replace("3 0 1 2", "3 0 1 -2"), False),
+        "nan_index.ply": (good.replace("property list uchar int", "property list uchar float").replace("3 0 1 2", "3 0 1 nan"), False),
+        "huge_index.ply": (good.replace("property list uchar int", "property list uchar double").replace("3 0 1 2", "3 0 1 4294967296"), False),
+        "count_text.ply": (good.replace("element face 1", "element face many"), False),
+        "count_negative.ply": (good.replace("element vertex 3", "element vertex -3"), False),
+        "no_props_huge.ply": ("ply\nformat ascii 1.0\nelement junk 18446744073709551615\nend_header\n", False),
+        "no_props_big.ply": ("ply\nformat ascii 1.0\nelement junk 4000000000\n" + head[len("ply\nformat ascii 1.0\n"):] + "end_header\n" + tri, False),
+        "vertex_claim.ply": (good.replace("element vertex 3", "element vertex 3000000000"), False),
+        "prop_noname.ply": (good.replace("property float z", "property float"), False),
+        "list_noname.ply": (good.replace("property list uchar int vertex_indices", "property list uchar int"), False),
+    }
+    for name, (text, ok) in cases.items():
+        f = tmp_path / name
+        f.write_text(text)
+        t0 = time.time()
+        st = lib.rt_host_scene_load(str(f).encode(), 1000, 15, C.byref(h))
+        assert time.time() - t0 < 5.0, name
+        assert (st == 0) == ok, (name, st)
+        if st == 0:
+            lib.rt_host_scene_free(h)
+    # binary: a list count larger than the rest of the file
+    b = tmp_path / "list_len.ply"
+    hdr = ("ply\nformat binary_little_endian 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+           "element face 1\nproperty list uint int vertex_indices\nend_header\n").encode()
+    b.write_bytes(hdr + struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0) + struct.pack("<I3i", 0xFFFFFFF0, 0, 1, 2))
+    assert lib.rt_host_scene_load(str(b).encode(), 1000, 15, C.byref(h)) == rt.capi.RT_ERR_IO
