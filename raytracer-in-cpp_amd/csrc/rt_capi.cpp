@@ -520,6 +520,14 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     c->S.queue_div = 12;          // (units / (waves x 12) per chunk: dodge 1.125 -> 1.112 ms against 6, measured at the kernel's full residency)
     if (const char *qd = std::getenv("RT_QUEUE_DIV")) { const int v = std::atoi(qd); if (v >= 1 && v <= 4096) c->S.queue_div = v; }
     c->S.shaft = (no_cull || std::getenv("RT_NO_SHAFT") != nullptr) ? 0 : 1;
+#ifdef RT_UNIT_HIST
+    {   // (leaked at rt_destroy: diagnostic build)
+        static uint32_t *dbg_buf = nullptr;
+        if (!dbg_buf && hipMalloc(reinterpret_cast<void **>(&dbg_buf), static_cast<size_t>(RT_UNIT_DBG_WORDS) * sizeof(uint32_t)) == hipSuccess)
+            (void)hipMemset(dbg_buf, 0, static_cast<size_t>(RT_UNIT_DBG_WORDS) * sizeof(uint32_t));
+        c->S.dbg = dbg_buf;
+    }
+#endif
     c->S.beam = (no_cull || std::getenv("RT_NO_BEAM") != nullptr) ? 0 : 1;
     if (sc->n_nodes >= (1u << 28)) { c->err = "rt_upload_scene: more than 2^28 nodes"; return RT_ERR_UNSUPPORTED; }
     c->flat = (sc->nodes[0].count_flags & RT_NODE_LEAF) && (sc->nodes[0].count_flags & 0x7fffffffu) <= 64u;
@@ -780,9 +788,19 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
     HIPCHK(c, hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
     { const rt_status os_ = check_overflow(c); if (os_ != RT_OK) return os_; }
     fold_stats(h);
-    if (std::getenv("RT_DEBUG")) std::fprintf(stderr, "RT_DEBUG level0: items %u tasks closest %u %u centre %u %u shadow %u %u\n", [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_items[0][sh * 16]; return t; }(), h.n_tasks[0][0], 0u, h.n_tasks[0][1], 0u, [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_task_sh[0][sh * 16]; return t; }(), 0u);
+    if (std::getenv("RT_DEBUG")) std::fprintf(stderr, "RT_DEBUG level0: items %u tasks closest %u %u centre %u %u shadow %u %u\n", [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_items[0][sh * 16]; return t; }(), [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_task_tr[0][0][sh * 16]; return t; }(), 0u, [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_task_tr[0][1][sh * 16]; return t; }(), 0u, [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_task_sh[0][sh * 16]; return t; }(), 0u);
     out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample;
     out->pixels = F.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;
+#ifdef RT_UNIT_HIST
+    if (!counted && c->S.dbg != nullptr) {
+        if (const char *dump = std::getenv("RT_UNIT_DUMP")) {
+            std::vector<uint32_t> hbuf(RT_UNIT_DBG_WORDS);
+            HIPCHK(c, hipMemcpy(hbuf.data(), c->S.dbg, hbuf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            if (FILE *f = std::fopen(dump, "wb")) { std::fwrite(hbuf.data(), sizeof(uint32_t), hbuf.size(), f); std::fclose(f); }
+        }
+        HIPCHK(c, hipMemset(c->S.dbg, 0, static_cast<size_t>(RT_UNIT_DBG_WORDS) * sizeof(uint32_t)));
+    }
+#endif
 #ifdef RT_PROFILE
     if (!counted) {
         std::fprintf(stderr, "RT_PROFILE ray-mode steps %llu useful %llu | tri-mode steps %llu useful %llu | box steps %llu useful %llu | leaves ray %llu tri %llu live-at-tri %llu | chunk-culled (ray,chunk) pairs %llu\n",
@@ -797,6 +815,18 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
                 unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += h.prof[72 + 8 * k + i];
                 std::fprintf(stderr, "RT_PROFILE k_shadow%s wave-cycles by phase (total %llu):", k ? "<CONT>" : "", tot);
                 for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s=%.1f%%", nm[i], tot ? 100.0 * double(h.prof[72 + 8 * k + i]) / double(tot) : 0.0);
+                std::fprintf(stderr, "\n");
+            }
+        }
+        {
+            static const char *nm2[8] = {"other", "group-load+cone-test / pop", "per-ray-children", "leaf-tri-mode", "leaf-scalar", "leaf-staged", "tile-setup", "-"};
+            for (int k = 0; k < 4; ++k) {         // stage 0 walk, stage 0 tasks, stage 1 walk, stage 1 tasks (level 0)
+                unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += h.prof[592 + 8 * k + i];
+                const int b = 624 + 4 * k;
+                const double span = (h.prof[b + 2] && h.prof[b + 3]) ? double(h.prof[b + 3] - ~h.prof[b + 2]) / 100.0 : 0.0;
+                std::fprintf(stderr, "RT_PROFILE k_stage<%d%s> waves %llu, lifetimes sum %.1f us, launch span %.1f us (busy %.0f%%), wave-cycles by phase (total %llu):", k / 2, (k & 1) ? ",CONT" : "",
+                             h.prof[b + 1], double(h.prof[b]) / 100.0, span, (span > 0 && h.prof[b + 1]) ? 100.0 * double(h.prof[b]) / 100.0 / (span * double(h.prof[b + 1])) : 0.0, tot);
+                for (int i = 0; i < 7; ++i) std::fprintf(stderr, " %s=%.1f%%", nm2[i], tot ? 100.0 * double(h.prof[592 + 8 * k + i]) / double(tot) : 0.0);
                 std::fprintf(stderr, "\n");
             }
         }

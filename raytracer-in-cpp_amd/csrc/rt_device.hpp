@@ -132,7 +132,11 @@ struct DScene {
     uint32_t n_bad_leaves;             // 0xffffffff: too many for the per-hit test -- such a chunk then blocks every beam that meets it
     int32_t beam;                      // k_beam before the shadow kernels: whole tiles of 64 lit hits whose sample rays nothing can block; RT_NO_BEAM=1 turns it off
     int32_t shaft;                     // k_shadow on tree scenes: shaft-culled group walk (rt_kernels.hip, shaft_walk); RT_NO_SHAFT=1 turns it off
+#ifdef RT_UNIT_HIST
+    uint32_t *dbg;                     // diagnostic build only: per-unit / per-wave records of the trace stages (rt_capi.cpp: RT_UNIT_DUMP)
+#endif
 };
+#define RT_UNIT_DBG_WORDS (4u * 65536u * 8u + 4u * 16384u * 4u)
 
 struct DCam {
     float center[3];
@@ -181,7 +185,11 @@ struct Control {
     uint32_t queue[3 * (RT_MAX_DEPTH + 1) + 4][RT_QUEUE_SHARDS * 16];
     uint32_t n_items[RT_MAX_DEPTH + 1][RT_LIST_SHARDS * 16];   // lit hits per level and shard (counter s at [s * 16])
     uint32_t n_rays[RT_MAX_DEPTH + 2][RT_LIST_SHARDS * 16];    // bounce rays per level and shard (n_rays[0][0] = rt_trace_rays input count)
-    uint32_t n_tasks[RT_MAX_DEPTH + 1][4];           // leaf tasks per level: closest q0 | centre q1 | (shadow: n_task_sh) | (spare)
+    // leaf tasks of the two traversal stages of the staged trace (closest hit q0 | light centre q1): RT_LIST_SHARDS sub-queues like
+    // n_task_sh below, each counter on its own 64-byte line.  (ONE word per stage made the walking launches atomic-bound: dodge at 1080p
+    // emits 5,878 + 3,417 tasks, one returning atomicAdd each, and one word serves ~88 of them per microsecond -- 67 and 39 us of the 80
+    // and 91 us those launches took, whatever the walk itself cost.)
+    uint32_t n_task_tr[RT_MAX_DEPTH + 1][2][RT_LIST_SHARDS * 16];
     // leaf tasks of the shadow kernels: RT_LIST_SHARDS sub-queues (producer block % RT_LIST_SHARDS), each counter on its own line --
     // one returning atomic per emitting leaf visit on a SINGLE word (~60k per dodge launch) ran into the ~88 per us limit
     uint32_t n_task_sh[RT_MAX_DEPTH + 1][RT_LIST_SHARDS * 16];

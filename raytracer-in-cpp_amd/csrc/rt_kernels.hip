@@ -301,7 +301,15 @@ struct WalkCtl {
 #ifdef RT_PROFILE
     PhaseClock *pc;
 #endif
+#ifdef RT_UNIT_HIST
+    uint32_t *dbg;                    // per-wave LDS: [0] groups popped, [1] leaf visits, [2] task emissions (returning atomics), [3] ray-mode triangles, [4] tri-mode (ray, chunk) steps, [5] chunk tests
+#endif
 };
+#ifdef RT_UNIT_HIST
+#define RT_DBG(wc, lane, i, v) do { if ((lane) == 0 && (wc).dbg) (wc).dbg[i] += (v); } while (0)
+#else
+#define RT_DBG(wc, lane, i, v) do { } while (0)
+#endif
 // (defined with the shaft code below)
 __device__ __forceinline__ bool tri_outside_cone(const float4 *rec, const TriRec &tr, const float m, const bool use_box);
 #ifndef RT_TRI_SHAFT_MIN
@@ -310,11 +318,11 @@ __device__ __forceinline__ bool tri_outside_cone(const float4 *rec, const TriRec
 #ifndef RT_RAYMODE_EXTRA
 #define RT_RAYMODE_EXTRA 8u          // scalar loads of the survivors' records
 #endif
-#ifdef RT_PROFILE
-__device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, 0u, 0u, nullptr, nullptr, 1u, 0u, seg_off(), 0ull, nullptr, false, nullptr}; }
-#else
-__device__ __forceinline__ WalkCtl walk_plain() { return WalkCtl{false, 0u, 0ull, 0u, 0u, 0u, 0u, nullptr, nullptr, 1u, 0u, seg_off(), 0ull, nullptr, false}; }
-#endif
+__device__ __forceinline__ WalkCtl walk_plain() {
+    WalkCtl w{};
+    w.target = 1u; w.seg = seg_off();
+    return w;
+}
 
 __device__ __forceinline__ TriRec tri_from_regs(const u32x16 &lo, const u32x4 &hi) {
     TriRec t;
@@ -338,7 +346,12 @@ __device__ __forceinline__ void tri_load_uniform2(const TriRec *p, TriRec &a, Tr
 }
 
 // same, for two records that are not neighbours
-__device__ __forceinline__ void tri_load_uniform_pair(const TriRec *pa, const TriRec *pb, TriRec &a, TriRec &b) {
+__device__ __forceinline__ const TriRec *uniform_ptr(const TriRec *p) {
+    // (folds away when the compiler already knows the value is wave-uniform; under SGPR pressure it may have parked the pointer in a VGPR)
+    return reinterpret_cast<const TriRec *>(uniform_u64(reinterpret_cast<unsigned long long>(p)));
+}
+__device__ __forceinline__ void tri_load_uniform_pair(const TriRec *pa_, const TriRec *pb_, TriRec &a, TriRec &b) {
+    const TriRec *pa = uniform_ptr(pa_), *pb = uniform_ptr(pb_);
     u32x16 lo0, lo1;
     u32x4 hi0, hi1;
     asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x40\n\ts_load_dwordx16 %2, %5, 0x0\n\ts_load_dwordx4 %3, %5, 0x40\n\ts_waitcnt lgkmcnt(0)"
@@ -373,7 +386,11 @@ struct PhaseClock {
     __device__ __forceinline__ void to(int p) { const long long t = clock64(); acc[cur] += t - last; last = t; cur = p; }
     __device__ __forceinline__ void flush(int lane, int base) { to(0); if (lane == 0 && g_prof) for (int i = 0; i < 8; ++i) atomicAdd(&g_prof[base + i], static_cast<unsigned long long>(acc[i])); }
 };
+#ifdef RT_NO_PHASE_CLOCK
+#define RT_PH(wc, p) do { } while (0)              // (make prof PROF_EXTRA=-DRT_NO_PHASE_CLOCK: unit-duration histograms without the clock reads)
+#else
 #define RT_PH(wc, p) do { if ((wc).pc) (wc).pc->to(p); } while (0)
+#endif
 #else
 #define RT_PH(wc, p) do { } while (0)
 #endif
@@ -422,6 +439,7 @@ __device__ __forceinline__ void leaf_visit(const DNode &nd, const uint32_t ni, c
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(wc.task_count, ntask);
         base = uniform_u32(base);
+        RT_DBG(wc, lane, 2, 1u);
         // The counter only ever grows (the consumer clamps it to the capacity): pieces that fall past the end of the
         // queue are simply processed here.  (Giving a failed reservation back with an atomicSub is unsound: a later
         // reservation can land inside the window and end up beyond the final count.)
@@ -438,6 +456,8 @@ __device__ __forceinline__ void leaf_visit(const DNode &nd, const uint32_t ni, c
         cb = static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * fit / ntask);       // the rest of the leaf, inline
     }
     RT_PROF_ADD(lane, tri_mode ? 7 : 6, 1);
+    RT_DBG(wc, lane, 1, 1u);
+    if (!tri_mode) RT_DBG(wc, lane, 3, cnt);
     RT_TILE_COUNT(stk, lane, tri_mode ? 1 : 0, cnt);
     RT_PH(wc, tri_mode ? 3 : (cnt <= RT_SCALAR_LEAF_MAX ? 4 : 5));
     if (tri_mode) {
@@ -462,6 +482,7 @@ __device__ __forceinline__ void leaf_visit(const DNode &nd, const uint32_t ni, c
             {
                 if (bd.never < 1.5f) {
                     RT_PROF_ADD(lane, 12, 1);
+                    RT_DBG(wc, lane, 5, 1u);
                     const float t0x = (bd.lo[0] - slab_pad - ox) * idx_, t1x = (bd.hi[0] + slab_pad - ox) * idx_;
                     const float t0y = (bd.lo[1] - slab_pad - oy) * idy_, t1y = (bd.hi[1] + slab_pad - oy) * idy_;
                     const float t0z = (bd.lo[2] - slab_pad - oz) * idz_, t1z = (bd.hi[2] + slab_pad - oz) * idz_;
@@ -539,6 +560,7 @@ __device__ __forceinline__ void leaf_visit(const DNode &nd, const uint32_t ni, c
                 const int r1 = two ? static_cast<int>(__builtin_ctzll(todo)) : r0;
                 if (two) todo &= todo - 1ull;
                 RT_PROF_ADD(lane, 2, two ? 2 : 1); RT_PROF_ADD(lane, 3, (two ? 2 : 1) * __popcll(__ballot(has_c)));
+                RT_DBG(wc, lane, 4, two ? 2u : 1u);
                 RT_TILE_COUNT(stk, lane, 2, two ? 2 : 1);
                 // Flyscene::rayTriangleIntersection, flyscene.cpp:787-819 (same operations as the ray-lane form)
                 float tq[2]; bool inq[2];
@@ -1330,6 +1352,145 @@ __device__ __forceinline__ void shaft_walk(const DNode *__restrict__ nodes, cons
     RT_PH(sl, 0);
 }
 
+// ======================================================================================================
+// CONE WALK -- BoxTree::intersect (boxTree.cpp:150-173) for the 64 rays of a closest-hit or light-centre packet, GROUP by group.
+//
+// The stack walk (packet_walk) pops ONE node and then fetches and tests its children one at a time, each behind a dependent 64-byte
+// scalar load: the walking launches of the trace stages issued at 4-13 % of the VALU rate, waiting on memory.  Here a stack entry is a
+// GROUP -- the children of one inner node -- and a popped group takes ONE round trip: lane = (child, test), every lane reads its
+// child's record (from the LDS copy of the top of the tree when the group lies there, else one vector load per lane, eight lanes
+// per 64-byte record), exactly the layout of the shaft walk.
+//
+// Packets whose rays share their ORIGIN o (a primary tile: the camera centre; the light-centre segments of a tile: the light) get the
+// shaft walk's separating tests with o as the apex: every point a ray reaches at any t >= 0 lies in the cone from o through the box
+// of the packet's targets, on the non-positive side of the six tangent planes through o (make_shaft_lanes with h := o, S := target
+// box).  A child whose CONTENT box lies strictly outside one plane holds no point a counted hit can have; so does one outside the AABB
+// of hull(o, targets) when counted hits lie before the targets (light-centre segments: t < 0.98).  A child whose OWN (padded) box lies
+// outside one plane is missed by every ray at every t >= 0: boxIntersect fails for all 64 by a margin far above the rounding of its
+// slab test (not claimed when a ray has a zero / non-finite direction component: 0/0 = NaN makes the reference's min/max chain
+// accept -- node_ok).  Only the surviving children are tested per ray (lane = ray) with the per-ray content test and the reference's
+// exact boxIntersect, their records broadcast from LDS or with v_readlane.  Packets without a common origin (bounce rays, lanes with
+// light lists of their own) skip the cone tests and keep the one-round-trip group fetch.
+// Leaves are visited as soon as the group that found them has been handled (closest hit: best_t then prunes what is still on the
+// stack), through leaf_visit with the cone record for its lane = triangle test.  The candidate set of every ray is unchanged: a leaf
+// is entered only through the exact per-ray tests of its whole ancestor chain.
+// ======================================================================================================
+struct ConeCtl {
+    bool have;           // the packet has a common origin and its lanes' coefficients sit in ShaftLds::shaft
+    bool node_ok;        // no ray of the packet has a zero / non-finite box-test direction component
+    bool box;            // counted hits lie before the targets: the near box bounds content too
+    float pad;           // padding of the tested boxes (>= the per-ray slab_pad: all rays start at the apex)
+};
+
+template <bool ANY>
+__device__ __forceinline__ void cone_walk(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris, const ChunkBound *__restrict__ chunks,
+                                          const uint32_t *__restrict__ leaf_chunk0, const WaveStack stk, const ShaftLds sl, const int lane, const WalkCtl &wc,
+                                          const DNode &root, const bool in_root, const RayLane &R, const float bx, const float by, const float bz,
+                                          const float brx, const float bry, const float brz, const ConeCtl CC, float &best_t, int &best_f, bool &occluded) {
+    const float ox = R.ox, oy = R.oy, oz = R.oz;
+    const unsigned long long m0 = __ballot(in_root);
+    if (m0 == 0ull) return;
+    const int tk = lane & 7, tc = lane >> 3;
+    int sp = 0, nleaf = 0;
+    uint32_t cnt_unused = 0u, sig_unused = 0u;
+    if (root.count_flags & RT_NODE_LEAF) {
+        if (lane == 0) { sl.lnode[0] = 0u; sl.lmask[0] = m0; }
+        nleaf = 1;
+    } else {
+        if (lane == 0) { stk.node[0] = root.first | ((root.count_flags & 0xfu) << 28); stk.mask[0] = m0; }
+        sp = 1;
+    }
+    while (sp > 0 || nleaf > 0) {
+        if (nleaf > 0) {
+            // the leaves the last group found (ONE inlined copy of the leaf code)
+            RT_PH(wc, 3);
+            for (int k = 0; k < nleaf; ++k) {
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t li = uniform_u32(sl.lnode[k]);
+                const unsigned long long lm = uniform_u64(sl.lmask[k]);
+                bool mine = ((lm >> lane) & 1ull) != 0ull;
+                if (ANY) mine = mine && !occluded;
+                const unsigned long long live = __ballot(mine);
+                if (live == 0ull) continue;
+                DNode nd;
+                if (li < sl.n_lds) { nd.first = sl.nodes[li].first; nd.count_flags = sl.nodes[li].count_flags; nd.pad[0] = sl.nodes[li].pad[0]; }
+                else { nd.first = nodes[li].first; nd.count_flags = nodes[li].count_flags; nd.pad[0] = nodes[li].pad[0]; }
+                nd.first = uniform_u32(nd.first); nd.count_flags = uniform_u32(nd.count_flags); nd.pad[0] = uniform_u32(nd.pad[0]);
+                leaf_visit<ANY, false, false>(nd, li, tris, chunks, leaf_chunk0, stk, lane, wc, R, live, mine, best_t, best_f, occluded, cnt_unused, sig_unused);
+            }
+            nleaf = 0;
+            continue;
+        }
+        --sp;
+        RT_PH(wc, 1);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t ent = uniform_u32(stk.node[sp]);
+        unsigned long long gm = uniform_u64(stk.mask[sp]);
+        if (ANY) gm &= ~__ballot(occluded);
+        if (gm == 0ull) continue;
+        const uint32_t base = ent & 0x0fffffffu, gcnt = ent >> 28;
+        // lane = (child tc, test tk): the child's record, then this lane's separating test on its content box and on its own box
+        const uint32_t ci = base + (static_cast<uint32_t>(tc) < gcnt ? static_cast<uint32_t>(tc) : 0u);
+        DNode ch;
+        const bool resident = base + gcnt <= sl.n_lds;
+        if (resident) ch = sl.nodes[ci];
+        else ch = nodes[ci];
+        unsigned long long surv;
+        if (CC.have) {
+            ShaftCtl SC{CC.pad, CC.node_ok};
+            const ShaftLanes SL = shaft_lanes_load(sl.shaft, tk, SC);
+            bool c_near, c_far, n_near, n_far;
+            shaft_lane_test(SL, tk, ch.clo[0] - SL.pad, ch.clo[1] - SL.pad, ch.clo[2] - SL.pad, ch.chi[0] + SL.pad, ch.chi[1] + SL.pad, ch.chi[2] + SL.pad, c_near, c_far);
+            shaft_lane_test(SL, tk, ch.bmin[0] - SL.pad, ch.bmin[1] - SL.pad, ch.bmin[2] - SL.pad, ch.bmax[0] + SL.pad, ch.bmax[1] + SL.pad, ch.bmax[2] + SL.pad, n_near, n_far);
+            // content: the planes, and the near box when the counted hits lie before the targets; own box: the planes only (the rays run on
+            // behind their targets, boxIntersect has no upper bound)
+            const unsigned long long b_c = __ballot(c_near && (tk < 6 || CC.box) && ch.pad[1] == 0u), b_n = __ballot(n_near && tk < 6);
+            const bool culled = (CC.node_ok && ballot_byte_any(b_n, lane)) || ballot_byte_any(b_c, lane);
+            surv = __ballot(static_cast<uint32_t>(lane) < gcnt && !culled);       // bit j: child j survives
+        } else {
+            surv = gcnt >= 64u ? ~0ull : ((1ull << gcnt) - 1ull);
+        }
+        RT_PROF_ADD(lane, 88, 1); RT_PROF_ADD(lane, 89, gcnt); RT_PROF_ADD(lane, 90, __popcll(surv));
+        RT_DBG(wc, lane, 0, 1u);
+        RT_PH(wc, 2);
+        while (surv != 0ull) {
+            const int j = static_cast<int>(__builtin_ctzll(surv));
+            surv &= surv - 1ull;
+            const DNode nd = resident ? sl.nodes[base + static_cast<uint32_t>(j)] : node_from_lane(ch, 8 * j);
+            bool h = ((gm >> lane) & 1ull) != 0ull;
+            if (ANY) h = h && !occluded;
+            RT_PROF_ADD(lane, 74, __popcll(__ballot(h)));
+            if (nd.pad[1] == 0u) {   // per-ray content test (as packet_walk): no countable point of the ray inside the subtree's content box
+                const float t0x = (nd.clo[0] - R.slab_pad - ox) * R.idx, t1x = (nd.chi[0] + R.slab_pad - ox) * R.idx;
+                const float t0y = (nd.clo[1] - R.slab_pad - oy) * R.idy, t1y = (nd.chi[1] + R.slab_pad - oy) * R.idy;
+                const float t0z = (nd.clo[2] - R.slab_pad - oz) * R.idz, t1z = (nd.chi[2] + R.slab_pad - oz) * R.idz;
+                const float tin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+                const float tout = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+                const bool miss = (tin > tout) || (tout < -1e-3f) ||
+                                  (ANY ? (tin > 0.981f) : (tin > best_t + 1e-3f * (1.0f + fabsf(best_t))));
+                h = h && !miss;
+                if (__ballot(h) == 0ull) continue;
+            }
+            h = h && box_hit_verified(nd.bmin, ox, oy, oz, bx, by, bz, brx, bry, brz);     // BoundingBox::boxIntersect, exact
+            RT_PROF_ADD(lane, 4, 1);
+            const unsigned long long hm = __ballot(h);
+            if (hm == 0ull) continue;
+            RT_PROF_ADD(lane, 91, 1); RT_PROF_ADD(lane, 75, __popcll(hm));
+            const uint32_t cj = base + static_cast<uint32_t>(j);
+            if (nd.count_flags & RT_NODE_LEAF) {
+                if ((nd.count_flags & 0x7fffffffu) == 0u) continue;
+                if (lane == 0) { sl.lnode[nleaf] = cj; sl.lmask[nleaf] = hm; }      // (at most 8 per group; the list is emptied before the next group)
+                ++nleaf;
+            } else {
+                if ((nd.count_flags & 0xfu) == 0u) continue;              // a "lost" node: no children
+                if (lane == 0) { stk.node[sp] = nd.first | ((nd.count_flags & 0xfu) << 28); stk.mask[sp] = hm; }
+                ++sp;
+            }
+        }
+    }
+    RT_PH(wc, 0);
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
@@ -1644,34 +1805,82 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
                                                           Control *__restrict__ ctl, float4 *__restrict__ rec,
                                                           int32_t *__restrict__ out_hit, float *__restrict__ out_t,
                                                           unsigned long long *best, unsigned long long *lit, const TaskQueues Q) {
-    __shared__ uint4 s_stage[RT_WAVES * RT_STAGE_TRIS * 5];
+    // GROUP: the walking launches of the two traversal stages (fast variants) take the cone walk -- groups of children in one round trip,
+    // the top of the tree in LDS -- and need no triangle staging buffer (leaf_visit<.., STAGED = false>); the counting variants and the
+    // leaf-task launches keep the stack walk.
+#ifdef RT_NO_GROUP_WALK
+    constexpr bool GROUP = false;                 // A/B build (make ab): the stack walk everywhere
+#else
+    constexpr bool GROUP = !COUNT && !CONT && STAGE < 2;
+#endif
+    constexpr bool CONE = GROUP || (CONT && STAGE < 2 && !COUNT);
+    __shared__ uint4 s_stage[GROUP ? 1 : RT_WAVES * RT_STAGE_TRIS * 5];
     __shared__ unsigned long long s_mask[RT_WAVES * RT_STACK];
     __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
-    __shared__ float4 s_cone[(CONT && STAGE < 2 && !COUNT) ? RT_WAVES * RT_SHAFT_TRI_REC : 1];
+    __shared__ float4 s_cone[CONE ? RT_WAVES * RT_SHAFT_TRI_REC : 1];
+    __shared__ uint4 s_top[GROUP ? RT_LDS_NODES * 4 : 1];           // the top of the octree: first RT_LDS_NODES DNodes (breadth-first order)
+    __shared__ unsigned long long s_lmask[GROUP ? RT_WAVES * RT_LEAF_SLOTS : 1];
+    __shared__ uint32_t s_lnode[GROUP ? RT_WAVES * RT_LEAF_SLOTS : 1];
+    __shared__ float4 s_shaft[GROUP ? RT_WAVES * 16 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const WaveStack stk{s_node + (false ? 0 : wave * RT_STACK), s_mask + (false ? 0 : wave * RT_STACK), s_stage + (false ? 0 : wave * RT_STAGE_TRIS * 5)};
-    float4 *const cone_rec = s_cone + ((CONT && STAGE < 2 && !COUNT) ? wave * RT_SHAFT_TRI_REC : 0);
+    const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, s_stage + (GROUP ? 0 : wave * RT_STAGE_TRIS * 5)};
+    float4 *const cone_rec = s_cone + (CONE ? wave * RT_SHAFT_TRI_REC : 0);
     ShardMap rmap{0u, 0u, 0u, 0u};
     if (!PRIMARY) rmap = shard_map(ctl->n_rays[level], lane, 0xffffffffu, 1u, 64u);
     const uint32_t ntiles = PRIMARY ? static_cast<uint32_t>(F.tiles_x) * static_cast<uint32_t>(F.tiles_y) : rmap.total;
+
+    uint32_t n_units = STAGE == 1 ? ntiles * static_cast<uint32_t>(lslots) : ntiles;
+    ShardMap tmap{0u, 0u, 0u, 0u};
+    if (CONT) {
+        tmap = shard_map(ctl->n_task_tr[level][Q.q_in & 1u], lane, Q.cap / RT_LIST_SHARDS, 1u, 1u);      // producers clamp to the per-shard capacity too
+        n_units = tmap.total;
+    }
+    if (n_units == 0u) return;                    // an empty bounce level / no leaf tasks: leave before any set-up (every wave takes this branch)
+    const uint32_t n_lds = GROUP ? (S.n_nodes < RT_LDS_NODES ? S.n_nodes : RT_LDS_NODES) : 0u;
+    if (GROUP) {
+        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(nodes);
+        for (uint32_t i = threadIdx.x; i < n_lds * 4u; i += blockDim.x) s_top[i] = src[i];
+        __syncthreads();
+    }
+    const ShaftLds sl{reinterpret_cast<const DNode *>(s_top), n_lds, s_lnode + (GROUP ? wave * RT_LEAF_SLOTS : 0), s_lmask + (GROUP ? wave * RT_LEAF_SLOTS : 0), cone_rec,
+                      s_shaft + (GROUP ? wave * 16 : 0)
+#ifdef RT_PROFILE
+                      , nullptr
+#endif
+    };
+    (void)sl;
     const DNode root = nodes[0];
     DCam cam;
     if (PRIMARY) cam = *camp;
 
-    uint32_t n_units = STAGE == 1 ? ntiles * static_cast<uint32_t>(lslots) : ntiles;
-    if (CONT) {
-        n_units = ctl->n_tasks[level][Q.q_in];
-        if (n_units > Q.cap) n_units = Q.cap;
-    }
     uint32_t c_rays = 0, c_cull = 0, c_centre = 0, c_box = 0, c_ref = 0;
     ShardedQueue q;
     q.init_static(n_units, gridDim.x * RT_WAVES, uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave)), lane);
+#ifdef RT_PROFILE
+    PhaseClock pclk; pclk.start();
+    const unsigned long long wave_t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
+#endif
+#ifdef RT_UNIT_HIST          // (make ab AB_FLAGS=-DRT_UNIT_HIST: the product kernels + two clock reads and one 32-byte record per unit, plain stores; RT_UNIT_DUMP=file)
+    __shared__ uint32_t s_dbg[RT_WAVES * 8];
+    const unsigned long long hist_t0 = static_cast<unsigned long long>(clock64());      // s_memtime (shader cycles); s_memrealtime serialises chip-wide
+    uint32_t hist_units = 0u;
+#endif
     for (uint32_t work = 0; q.next(work);) {
         uint32_t unit = work;
         WalkCtl wc = walk_plain();
         RT_PROF_ADD(lane, 13, 1);
+#ifdef RT_PROFILE
+        if (STAGE < 2 && !COUNT) { wc.pc = &pclk; pclk.to(6); }
+#endif
+#ifdef RT_UNIT_HIST
+        const unsigned long long unit_t0 = static_cast<unsigned long long>(clock64());
+        wc.dbg = s_dbg + wave * 8;
+        if (lane == 0) for (int k = 0; k < 6; ++k) wc.dbg[k] = 0u;
+#endif
         if (CONT) {
-            const ContTask task = Q.tasks_in[work];
+            uint32_t tsh, tloc, tn;
+            shard_find(tmap, work, tsh, tloc, tn);
+            const ContTask task = Q.tasks_in[tsh * (Q.cap / RT_LIST_SHARDS) + tloc];
             unit = uniform_u32(task.unit);
             wc.resume = true;
             wc.start_node = uniform_u32(task.node);
@@ -1680,7 +1889,8 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
             wc.c_end = uniform_u32(task.c_end);
         }
         if (STAGE < 2 && Q.tasks_out != nullptr && Q.budget != 0u) {
-            wc.budget = Q.budget; wc.unit = unit; wc.tasks = Q.tasks_out; wc.task_count = &ctl->n_tasks[level][Q.q_out]; wc.task_cap = Q.cap;
+            const uint32_t tsh = blockIdx.x & (RT_LIST_SHARDS - 1u), tcap = Q.cap / RT_LIST_SHARDS;      // sharded task queue (Control::n_task_tr)
+            wc.budget = Q.budget; wc.unit = unit; wc.tasks = Q.tasks_out + tsh * tcap; wc.task_count = &ctl->n_task_tr[level][Q.q_out & 1u][tsh * 16u]; wc.task_cap = tcap;
             wc.target = Q.target ? Q.target : Q.budget;
         }
         const uint32_t tile = STAGE == 1 ? unit / static_cast<uint32_t>(lslots) : unit;
@@ -1691,6 +1901,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
         // lanes in `on` (exact wave min / max).  Only the leaf-task launches build it: there every unit is a run of 64-triangle chunks of a big
         // leaf (cfg4: closest-hit tasks 0.92 -> 0.68 ms, light-centre tasks 0.55 -> 0.48 ms), while on the walking launches the ~200
         // instructions per tile cost more than the few big leaves they keep inline return (dodge: +7 us on both)
+        ConeCtl CC{false, false, false, 0.f};
         auto set_cone = [&](const bool on, const float ax, const float ay, const float az, const float tx, const float ty, const float tz, const bool box) {
             float lx = on ? tx : 3e38f, ly = on ? ty : 3e38f, lz = on ? tz : 3e38f, hx_ = on ? tx : -3e38f, hy_ = on ? ty : -3e38f, hz_ = on ? tz : -3e38f;
 #pragma unroll
@@ -1701,8 +1912,15 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
             const ShaftLanes SLc = make_shaft_lanes(lane, ax, ay, az, lx, ly, lz, hx_, hy_, hz_, S.extent);
             __builtin_amdgcn_wave_barrier();
             shaft_tri_store(cone_rec, lane, SLc, ax, ay, az, lx, ly, lz, hx_, hy_, hz_);
+            if (GROUP) shaft_lanes_store(sl.shaft, lane, SLc);
             __builtin_amdgcn_wave_barrier();
             wc.cone = cone_rec; wc.cone_box = box;
+            // (every ray of the packet starts at the apex: the group tests pad their boxes by the per-ray slab_pad of that origin)
+            CC.have = true; CC.box = box; CC.pad = 4e-4f * (fabsf(ax) + fabsf(ay) + fabsf(az) + S.extent) * 1.001f;
+        };
+        // no ray of the packet with a zero / non-finite component of its box-test direction (see cone_walk)
+        auto dirs_ok = [&](const bool on, const float vx, const float vy, const float vz) -> bool {
+            return __ballot(on && !(fabsf(vx) > 0.0f && fabsf(vy) > 0.0f && fabsf(vz) > 0.0f && fabsf(vx) + fabsf(vy) + fabsf(vz) < 3e38f)) == 0ull;
         };
 
         if (STAGE == 0) {
@@ -1717,13 +1935,19 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
                 in_root = in_root && box_hit_verified(root.bmin, r.ox, r.oy, r.oz, bx, by, bz, brx, bry, brz);
             }
             // (primary tiles: every ray starts at the camera centre and runs through its screen point o + d)
-            if (CONT && PRIMARY && !COUNT && __ballot(in_root) != 0ull) set_cone(r.pre, r.ox, r.oy, r.oz, r.ox + r.dx, r.oy + r.dy, r.oz + r.dz, false);
+            if ((CONT || GROUP) && PRIMARY && !COUNT && __ballot(in_root) != 0ull) set_cone(r.pre, r.ox, r.oy, r.oz, r.ox + r.dx, r.oy + r.dy, r.oz + r.dz, false);
             float best_t = 3.402823466e+38f;
             int best_f = -1;
             bool dummy = false;
             uint32_t sig_unused = 0u;
-            packet_walk<false, COUNT>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, wc, in_root, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz,
-                                      bx, by, bz, brx, bry, brz, best_t, best_f, dummy, c_box, c_ref, sig_unused);
+            if (GROUP) {
+                CC.node_ok = dirs_ok(in_root, bx, by, bz);
+                const RayLane R{r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, brx, bry, brz, 4e-4f * (fabsf(r.ox) + fabsf(r.oy) + fabsf(r.oz) + S.extent)};
+                cone_walk<false>(nodes, tris, chunks, leaf_chunk0, stk, sl, lane, wc, root, in_root, R, bx, by, bz, brx, bry, brz, CC, best_t, best_f, dummy);
+            } else {
+                packet_walk<false, COUNT>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, wc, in_root, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz,
+                                          bx, by, bz, brx, bry, brz, best_t, best_f, dummy, c_box, c_ref, sig_unused);
+            }
             const bool found = best_f >= 0 && static_cast<uint32_t>(best_f) < S.n_faces;
             const unsigned long long key = found ? ((static_cast<unsigned long long>(__float_as_uint(best_t)) << 32) | static_cast<uint32_t>(best_f))
                                                  : RT_NO_HIT_KEY;
@@ -1755,12 +1979,18 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
                     sroot = act && box_hit_verified(root.bmin, px, py, pz, sdx, sdy, sdz, srx, sry, srz);
                 }
                 // (every segment starts at the light: one cone per (tile, light) unless the lanes carry lights of their own)
-                if (CONT && !COUNT && __ballot(act && r.lmode != 0u) == 0ull && __ballot(sroot) != 0ull) set_cone(act, L.pos[l][0], L.pos[l][1], L.pos[l][2], hx, hy, hz, true);
+                if ((CONT || GROUP) && !COUNT && __ballot(act && r.lmode != 0u) == 0ull && __ballot(sroot) != 0ull) set_cone(act, L.pos[l][0], L.pos[l][1], L.pos[l][2], hx, hy, hz, true);
                 float t_unused = 0.f; int f_unused = -1;
                 bool occ = false;
                 uint32_t sig_unused = 0u;
-                packet_walk<true, COUNT>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, wc, sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz,
-                                         srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref, sig_unused);
+                if (GROUP) {
+                    CC.node_ok = dirs_ok(sroot, sdx, sdy, sdz);
+                    const RayLane R{px, py, pz, sdx, sdy, sdz, srx, sry, srz, 4e-4f * (fabsf(px) + fabsf(py) + fabsf(pz) + S.extent)};
+                    cone_walk<true>(nodes, tris, chunks, leaf_chunk0, stk, sl, lane, wc, root, sroot, R, sdx, sdy, sdz, srx, sry, srz, CC, t_unused, f_unused, occ);
+                } else {
+                    packet_walk<true, COUNT>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, wc, sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz,
+                                             srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref, sig_unused);
+                }
                 if (CONT) {
                     const unsigned long long om = __ballot(act && occ);
                     if (lane == 0 && om != 0ull) atomicAnd(&lit[lit_index], ~om);
@@ -1795,7 +2025,46 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
                 }
             }
         }
+#ifdef RT_UNIT_HIST
+        if (STAGE < 2 && !COUNT && level == 0 && S.dbg != nullptr) {
+            // record of this unit: kernel k = 2 STAGE + CONT, slot `work` (< 65536): cycles / 16, the six step counters, the wave
+            const unsigned long long dtu = (static_cast<unsigned long long>(clock64()) - unit_t0) >> 4;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t kk = 2u * STAGE + (CONT ? 1u : 0u);
+            if (work < 65536u && lane < 8) {
+                uint32_t v = lane == 0 ? static_cast<uint32_t>(dtu) : (lane < 7 ? s_dbg[wave * 8 + lane - 1] : blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave));
+                S.dbg[(static_cast<size_t>(kk) * 65536u + work) * 8u + static_cast<uint32_t>(lane)] = v;
+            }
+            ++hist_units;
+        }
+#endif
     }
+#ifdef RT_PROFILE
+    if (STAGE < 2 && !COUNT && level == 0) {
+        // phase clocks of the level-0 trace stages: prof[592 + 16 * STAGE + 8 * CONT + phase]; wave lifetimes (10 ns ticks): sum / waves / first start / last end
+        pclk.flush(lane, 592 + 16 * STAGE + (CONT ? 8 : 0));
+        if (lane == 0 && g_prof) {
+            const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+            const int b = 624 + 8 * STAGE + (CONT ? 4 : 0);
+            atomicAdd(&g_prof[b], t1 - wave_t0); atomicAdd(&g_prof[b + 1], 1ull);
+            atomicMax(&g_prof[b + 2], ~wave_t0);
+            atomicMax(&g_prof[b + 3], t1);
+        }
+    }
+#endif
+#ifdef RT_UNIT_HIST
+    if (STAGE < 2 && !COUNT && level == 0 && lane == 0 && S.dbg != nullptr) {
+        // record of this wave (after the unit records: 4 x 65536 x 8 words): kernel k, wave id < 16384: lifetime / 16, units, XCC id
+        const unsigned long long t1 = static_cast<unsigned long long>(clock64());
+        const uint32_t wid = blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave), kk = 2u * STAGE + (CONT ? 1u : 0u);
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (wid < 16384u) {
+            uint32_t *wp = S.dbg + static_cast<size_t>(4u) * 65536u * 8u + (static_cast<size_t>(kk) * 16384u + wid) * 4u;
+            wp[0] = static_cast<uint32_t>((t1 - hist_t0) >> 4); wp[1] = hist_units; wp[2] = xcc & 7u; wp[3] = static_cast<uint32_t>(hist_t0 >> 4);
+        }
+    }
+#endif
     c_rays = wave_sum(c_rays); c_cull = wave_sum(c_cull); c_centre = wave_sum(c_centre);
     if (COUNT) { c_box = wave_sum(c_box); c_ref = wave_sum(c_ref); }
     if (lane == 0) {
@@ -2321,10 +2590,14 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         unsigned long long sbin = (wave_t0 > org ? wave_t0 - org : 0ull) / 5000ull;
         if (sbin > 39ull) sbin = 39ull;
         atomicAdd(&g_prof[520 + sbin], 1ull);
+#ifdef RT_PROFILE_XCC            // (per-XCD end-time bins: [160, 480) now holds the unit-duration histograms of the trace stages)
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         atomicAdd(&g_prof[160 + (xcc & 7u) * 40u + bin], 1ull);
         atomicAdd(&g_prof[500 + (xcc & 7u)], static_cast<unsigned long long>(c_rays_dbg));
+#else
+        (void)c_rays_dbg;
+#endif
     }
 #endif
     c_rays = wave_sum(c_rays);

@@ -161,6 +161,8 @@ def test_sphere_graph_survives_later_sphere_calls(rt, scene):
     w, h = 160, 96
     cam = rt.default_camera(w, h)
     p = rt.make_params(w, h, 2)
+    # (size the frame buffers for four visibility words per pair first: a later growth would -- rightly -- invalidate the graph)
+    render_gpu(rt, ctx, cam, rt.make_lights(area=True, usteps=16, vsteps=16), w, h, 2)
     off_a = rt.sphere_offsets(65, 1.0, 64)
     L_a = rt.set_sphere(rt.make_lights(area=False), off_a)
     want, _ = render_gpu(rt, ctx, cam, L_a, w, h, 2)

@@ -16,5 +16,6 @@ fs = pkg.Flyscene(scene_path=path)
 fs.initialize(w, h, True, False)
 fs.usteps = fs.vsteps = u
 fs.max_depth = d
-fs.raytraceScene(w, h, write_ppm=False, collect_stats=True)
+for _ in range(3):
+    fs.raytraceScene(w, h, write_ppm=False)
 print("rays", fs.stats.total_rays(), "items", fs.stats.shaded_hits)

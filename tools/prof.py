@@ -17,6 +17,9 @@ fs = pkg.Flyscene(scene_path=path)
 fs.initialize(w, h, True, False)
 fs.usteps = fs.vsteps = u
 fs.max_depth = d
-fs.raytraceScene(w, h, write_ppm=False)
+for rep in range(3):          # the last frame is the warm one: read ITS lines
+    sys.stderr.write("RT_PROFILE ---- frame %d\n" % rep)
+    sys.stderr.flush()
+    fs.raytraceScene(w, h, write_ppm=False)
 st = fs.stats
 print("rays", st.total_rays(), "items", st.shaded_hits, "ms", st.ms_trace, st.ms_shadow, st.ms_shade)
