@@ -80,6 +80,7 @@ struct rt_ctx {
     ContTask *d_tasks[2] = {nullptr, nullptr};   // continuation queues of k_shadow (tree scenes)
     uint32_t task_cap = 1u << 21;
     uint32_t trace_budget = 1000u;              // leaves above this estimated cost (VALU instructions) become tasks (0 = off)
+    uint32_t group_budget = 4u;                 // groups a trace unit pops before it hands the rest of its stack to the task launch (RT_GROUP_BUDGET, 0 = never)
     uint32_t shadow_budget = 3000u;
     bool beam_trees = false;
     int shaft_min_samples = 33;           // tree scenes: sample counts from which a (hit, light) pair gets a wave of its own (k_shadow_shaft)
@@ -155,6 +156,7 @@ extern "C" rt_status rt_create(rt_ctx **out, int device) {
     if (const char *tc = std::getenv("RT_TASK_CAP")) { const long v = std::atol(tc); if (v >= 64 && v <= (1l << 24)) c->task_cap = static_cast<uint32_t>(v); }
     if (const char *tt = std::getenv("RT_TASK_TARGET")) c->task_target = static_cast<uint32_t>(std::atoi(tt));
     if (const char *tb = std::getenv("RT_TRACE_BUDGET")) c->trace_budget = static_cast<uint32_t>(std::atoi(tb));
+    if (const char *gb = std::getenv("RT_GROUP_BUDGET")) c->group_budget = static_cast<uint32_t>(std::atoi(gb));
     if (const char *gm = std::getenv("RT_GRID_MULT")) {          // tuning knob: grid = CUs x residency x mult
         const int m = std::atoi(gm);
         if (m > 0 && m <= 64) c->grid_mult = m;
@@ -701,7 +703,7 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
             for (int stage = 0; stage < 2; ++stage) {
                 const uint32_t q0 = static_cast<uint32_t>(stage);
                 launch_stage(prim, count, stage, false, tgrid * c->stage_mult, st, c->S, c->d_cam, L, F, level, lslots, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
-                             hit_l, t_l, c->d_best, c->d_lit, TaskQueues{nullptr, B ? c->d_tasks[stage] : nullptr, 0u, q0, cap, B, c->task_target});
+                             hit_l, t_l, c->d_best, c->d_lit, TaskQueues{nullptr, B ? c->d_tasks[stage] : nullptr, 0u, q0, cap, B, c->task_target, count ? 0u : c->group_budget});
                 if (B != 0u)
                     launch_stage(prim, false, stage, true, tgrid, st, c->S, c->d_cam, L, F, level, lslots, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
                                  hit_l, t_l, c->d_best, c->d_lit, TaskQueues{c->d_tasks[stage], nullptr, q0, 0u, cap, 0u});

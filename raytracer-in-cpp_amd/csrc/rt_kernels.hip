@@ -1382,25 +1382,66 @@ struct ConeCtl {
     float pad;           // padding of the tested boxes (>= the per-ray slab_pad: all rays start at the apex)
 };
 
+// What a cone walk hands to the task launch that follows, and where it starts.
+//   * Work is handed away in ONE reservation per unit: the leaves whose estimated cost exceeds `budget` and -- once the unit has popped
+//     `group_budget` groups -- the groups still on its stack are collected in a per-wave pending list and written as tasks with a single
+//     returning atomicAdd when the walk runs dry.  (Measured on dodgeColorTest.obj at 1080p, per-unit records of the diagnostic build: the
+//     walking launches of both stages last exactly as long as their longest unit -- 150 k / 260 k cycles against a mean wave lifetime of
+//     28 k / 16 k -- and such a unit is 10-16 groups at ~4 k cycles, 6-23 leaf visits at 2-6 k and 7-11 task reservations at 2-3 k
+//     each: a serial chain, not a throughput problem.  The task launches were bound the same way by single (chunk, 64 rays) pieces.)
+//   * A leaf piece is a chunk range AND a subset of the rays: a piece of one 64-triangle chunk for 64 rays is ~3,700 instructions, so
+//     pieces that cannot be cut by chunks any more are cut by rays (up to four parts of the lane mask).
+//   * The task launch runs the same walk from a task: kind 1 = a group entry (the children of an inner node) with its ray mask,
+//     kind 2 = chunks [c_begin, c_end) of a leaf.  It hands nothing on.
+#define RT_PEND_SLOTS 32
+struct ConeTasks {
+    ContTask *tasks;               // nullptr / budget 0: keep everything inline
+    uint32_t *count;
+    uint32_t cap, budget, target, group_budget, unit;
+    uint32_t start_kind;           // 0: the root; 1: group entry `start_node`; 2: leaf `start_node`, chunks [start_cb, start_ce)
+    uint32_t start_node, start_cb, start_ce;
+    unsigned long long start_mask;
+};
+struct ConeLds {
+    uint32_t *pnode;               // per-wave pending list (RT_PEND_SLOTS): node / group entry ...
+    unsigned long long *pmask;     // ... ray mask ...
+    uint32_t *pinfo;               // ... bit 31: group entry; bit 30: to be processed inline (queue full); low bits: first chunk of the inline part
+    uint32_t *lcb, *lce;           // per-wave leaf list: chunk range of the visit (lcb = 0xffffffff: a fresh leaf, all chunks, may still be handed away)
+};
+
+// estimated cost of one leaf visit in VALU instructions and the lane mapping it would take (leaf_visit decides the same way)
+__device__ __forceinline__ uint32_t leaf_cost(const uint32_t cnt, const unsigned long long live, const bool staged) {
+    const uint32_t nchunk = (cnt + 63u) >> 6;
+    const uint32_t tri_cost = nchunk * RT_COST_CHUNK_TEST + static_cast<uint32_t>(__popcll(live)) * ((nchunk + 2u) / 3u) * RT_COST_TRI_MODE;
+    const bool tri_mode = (!staged && cnt > RT_SCALAR_LEAF_MAX) || tri_cost < cnt * RT_COST_RAY_MODE;
+    return tri_mode ? tri_cost : cnt * RT_COST_RAY_MODE;
+}
+
 template <bool ANY>
 __device__ __forceinline__ void cone_walk(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris, const ChunkBound *__restrict__ chunks,
-                                          const uint32_t *__restrict__ leaf_chunk0, const WaveStack stk, const ShaftLds sl, const int lane, const WalkCtl &wc,
-                                          const DNode &root, const bool in_root, const RayLane &R, const float bx, const float by, const float bz,
-                                          const float brx, const float bry, const float brz, const ConeCtl CC, float &best_t, int &best_f, bool &occluded) {
+                                          const uint32_t *__restrict__ leaf_chunk0, const WaveStack stk, const ShaftLds sl, const ConeLds cl, const int lane,
+                                          const WalkCtl &wc, const ConeTasks &TQ, const DNode &root, const bool in_root, const RayLane &R, const float bx, const float by,
+                                          const float bz, const float brx, const float bry, const float brz, const ConeCtl CC, float &best_t, int &best_f, bool &occluded) {
     const float ox = R.ox, oy = R.oy, oz = R.oz;
-    const unsigned long long m0 = __ballot(in_root);
+    unsigned long long m0 = __ballot(in_root);
+    if (TQ.start_kind != 0u) m0 &= TQ.start_mask;
     if (m0 == 0ull) return;
     const int tk = lane & 7, tc = lane >> 3;
-    int sp = 0, nleaf = 0;
+    int sp = 0, nleaf = 0, npend = 0;
+    uint32_t groups_done = 0u;
+    bool hand_away = TQ.tasks != nullptr && (TQ.budget != 0u || TQ.group_budget != 0u);
     uint32_t cnt_unused = 0u, sig_unused = 0u;
-    if (root.count_flags & RT_NODE_LEAF) {
-        if (lane == 0) { sl.lnode[0] = 0u; sl.lmask[0] = m0; }
+    if (TQ.start_kind == 2u || (TQ.start_kind == 0u && (root.count_flags & RT_NODE_LEAF))) {
+        if (lane == 0) {
+            cl.lcb[0] = TQ.start_kind == 2u ? TQ.start_cb : 0xffffffffu; cl.lce[0] = TQ.start_kind == 2u ? TQ.start_ce : 0xffffffffu;
+            sl.lnode[0] = TQ.start_kind == 2u ? TQ.start_node : 0u; sl.lmask[0] = m0;
+        }
         nleaf = 1;
     } else {
-        if (lane == 0) { stk.node[0] = root.first | ((root.count_flags & 0xfu) << 28); stk.mask[0] = m0; }
+        if (lane == 0) { stk.node[0] = TQ.start_kind == 1u ? TQ.start_node : (root.first | ((root.count_flags & 0xfu) << 28)); stk.mask[0] = m0; }
         sp = 1;
     }
-    while (sp > 0 || nleaf > 0) {
+    for (;;) {
         if (nleaf > 0) {
             // the leaves the last group found (ONE inlined copy of the leaf code)
             RT_PH(wc, 3);
@@ -1408,6 +1449,7 @@ __device__ __forceinline__ void cone_walk(const DNode *__restrict__ nodes, const
                 __builtin_amdgcn_wave_barrier();
                 const uint32_t li = uniform_u32(sl.lnode[k]);
                 const unsigned long long lm = uniform_u64(sl.lmask[k]);
+                const uint32_t cb = uniform_u32(cl.lcb[k]), ce = uniform_u32(cl.lce[k]);
                 bool mine = ((lm >> lane) & 1ull) != 0ull;
                 if (ANY) mine = mine && !occluded;
                 const unsigned long long live = __ballot(mine);
@@ -1416,12 +1458,120 @@ __device__ __forceinline__ void cone_walk(const DNode *__restrict__ nodes, const
                 if (li < sl.n_lds) { nd.first = sl.nodes[li].first; nd.count_flags = sl.nodes[li].count_flags; nd.pad[0] = sl.nodes[li].pad[0]; }
                 else { nd.first = nodes[li].first; nd.count_flags = nodes[li].count_flags; nd.pad[0] = nodes[li].pad[0]; }
                 nd.first = uniform_u32(nd.first); nd.count_flags = uniform_u32(nd.count_flags); nd.pad[0] = uniform_u32(nd.pad[0]);
-                leaf_visit<ANY, false, false>(nd, li, tris, chunks, leaf_chunk0, stk, lane, wc, R, live, mine, best_t, best_f, occluded, cnt_unused, sig_unused);
+                const bool fresh = cb == 0xffffffffu;
+                if (fresh && hand_away && TQ.budget != 0u && npend < RT_PEND_SLOTS && leaf_cost(nd.count_flags & 0x7fffffffu, live, false) > TQ.budget) {
+                    if (lane == 0) { cl.pnode[npend] = li; cl.pmask[npend] = live; cl.pinfo[npend] = 0u; }
+                    ++npend;
+                    continue;
+                }
+                WalkCtl wl = wc;
+                wl.budget = 0u; wl.tasks = nullptr;
+                if (!fresh) { wl.resume = true; wl.c_begin = cb; wl.c_end = ce; }
+                leaf_visit<ANY, false, false>(nd, li, tris, chunks, leaf_chunk0, stk, lane, wl, R, live, mine, best_t, best_f, occluded, cnt_unused, sig_unused);
             }
             nleaf = 0;
             continue;
         }
+        if (npend > 0 && !hand_away) {
+            // (the task queue was full: the pending work comes back, as many leaves at a time as the leaf list holds)
+            __builtin_amdgcn_wave_barrier();
+            while (npend > 0 && nleaf < RT_LEAF_SLOTS) {
+                --npend;
+                const uint32_t pn = uniform_u32(cl.pnode[npend]), pi = uniform_u32(cl.pinfo[npend]);
+                const unsigned long long pm = uniform_u64(cl.pmask[npend]);
+                if (pi & 0x80000000u) { if (lane == 0) { stk.node[sp] = pn; stk.mask[sp] = pm; } ++sp; }
+                else { if (lane == 0) { sl.lnode[nleaf] = pn; sl.lmask[nleaf] = pm; cl.lcb[nleaf] = pi & 0x3fffffffu; cl.lce[nleaf] = 0xffffffffu; } ++nleaf; }
+            }
+            continue;
+        }
+        // a unit that has popped its share of groups hands the rest of its stack away
+        if (hand_away && TQ.group_budget != 0u && sp > 0 && groups_done >= TQ.group_budget && npend + sp <= RT_PEND_SLOTS) {
+            __builtin_amdgcn_wave_barrier();
+            for (int k = 0; k < sp; ++k) {
+                const uint32_t ent = uniform_u32(stk.node[k]);
+                const unsigned long long em = uniform_u64(stk.mask[k]);
+                if (lane == 0) { cl.pnode[npend] = ent; cl.pmask[npend] = em; cl.pinfo[npend] = 0x80000000u; }
+                ++npend;
+            }
+            sp = 0;
+        }
+        if (sp == 0) {
+            if (npend == 0) break;
+            // ---- ONE reservation for everything this unit hands away.  Lane e prices pending entry e.
+            __builtin_amdgcn_wave_barrier();
+            const bool mine_e = lane < npend;
+            const uint32_t e_node = mine_e ? cl.pnode[lane] : 0u, e_info = mine_e ? cl.pinfo[lane] : 0u;
+            const unsigned long long e_mask = mine_e ? cl.pmask[lane] : 0ull;
+            const bool e_group = (e_info & 0x80000000u) != 0u;
+            uint32_t e_cnt = 0u;
+            if (mine_e && !e_group) e_cnt = (e_node < sl.n_lds ? sl.nodes[e_node].count_flags : nodes[e_node].count_flags) & 0x7fffffffu;
+            const uint32_t e_nchunk = (e_cnt + 63u) >> 6;
+            const uint32_t e_rays = static_cast<uint32_t>(__popcll(e_mask));
+            uint32_t e_npc = 1u, e_nrs = 1u;                      // chunk pieces x ray parts
+            if (mine_e && !e_group) {
+                const uint32_t est = leaf_cost(e_cnt, e_mask, false);
+                uint32_t ntask = (est + TQ.target - 1u) / TQ.target;
+                if (ntask < 1u) ntask = 1u;
+                e_npc = ntask < e_nchunk ? ntask : e_nchunk;
+                e_nrs = (ntask + e_npc - 1u) / e_npc;
+                if (e_nrs > 4u) e_nrs = 4u;
+                if (e_nrs > e_rays) e_nrs = e_rays;
+                if (e_nrs < 1u) e_nrs = 1u;
+            }
+            const uint32_t e_pieces = mine_e ? e_npc * e_nrs : 0u;
+            uint32_t incl = e_pieces;
+            for (int d = 1; d < RT_PEND_SLOTS; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += t;
+            }
+            const uint32_t total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), RT_PEND_SLOTS - 1));
+            uint32_t base = 0u;
+            if (lane == 0) base = atomicAdd(TQ.count, total);
+            base = uniform_u32(base);
+            RT_DBG(wc, lane, 2, 1u);
+            // (the counter only grows, the consumer clamps it: what falls past the end of the queue is processed here, and the unit stops handing work away)
+            const uint32_t room = base >= TQ.cap ? 0u : TQ.cap - base;
+            int kept = 0;
+            for (int e = 0; e < npend; ++e) {
+                const uint32_t off = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl - e_pieces), e));
+                const uint32_t pieces = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e_pieces), e));
+                const uint32_t npc = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e_npc), e));
+                const uint32_t nrs = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e_nrs), e));
+                const uint32_t nchunk = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e_nchunk), e));
+                const uint32_t node = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(e_node), e));
+                const bool group = __builtin_amdgcn_readlane(static_cast<int>(e_group ? 1 : 0), e) != 0;
+                const unsigned long long M = uniform_u64(cl.pmask[e]);
+                const uint32_t fit = off >= room ? 0u : (pieces < room - off ? pieces : room - off);
+                // the ray parts of this entry's mask: lanes of equal rank share a part
+                const bool in_m = ((M >> lane) & 1ull) != 0ull;
+                const uint32_t rank = lanes_below(M), pc = static_cast<uint32_t>(__popcll(M));
+                const uint32_t part = (rank * nrs) / (pc ? pc : 1u);
+                unsigned long long sub[4];
+#pragma unroll
+                for (uint32_t r = 0; r < 4u; ++r) sub[r] = __ballot(in_m && part == r);
+                for (uint32_t i = static_cast<uint32_t>(lane); i < fit; i += 64u) {
+                    const uint32_t ci = i / nrs, rp = i - ci * nrs;
+                    ContTask t;
+                    t.unit = TQ.unit; t.node = node;
+                    t.mask = nrs == 1u ? M : (rp == 0u ? sub[0] : (rp == 1u ? sub[1] : (rp == 2u ? sub[2] : sub[3])));
+                    t.c_begin = group ? 0u : static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * ci / npc);
+                    t.c_end = group ? 0u : static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * (ci + 1u) / npc);
+                    t.pad0 = group ? 1u : 2u; t.pad1 = 0u;
+                    TQ.tasks[base + off + i] = t;
+                }
+                if (fit < pieces) {
+                    // inline from the first chunk piece that did not go out whole (its earlier ray parts are simply done twice: the results merge)
+                    const uint32_t cb0 = group ? 0u : static_cast<uint32_t>(static_cast<unsigned long long>(nchunk) * (fit / nrs) / npc);
+                    if (lane == 0) { cl.pnode[kept] = node; cl.pmask[kept] = M; cl.pinfo[kept] = (group ? 0x80000000u : 0u) | 0x40000000u | cb0; }
+                    ++kept;
+                }
+            }
+            npend = kept;
+            if (kept > 0) hand_away = false;
+            continue;
+        }
         --sp;
+        ++groups_done;
         RT_PH(wc, 1);
         __builtin_amdgcn_wave_barrier();
         const uint32_t ent = uniform_u32(stk.node[sp]);
@@ -1453,13 +1603,11 @@ __device__ __forceinline__ void cone_walk(const DNode *__restrict__ nodes, const
         RT_PROF_ADD(lane, 88, 1); RT_PROF_ADD(lane, 89, gcnt); RT_PROF_ADD(lane, 90, __popcll(surv));
         RT_DBG(wc, lane, 0, 1u);
         RT_PH(wc, 2);
-        while (surv != 0ull) {
-            const int j = static_cast<int>(__builtin_ctzll(surv));
-            surv &= surv - 1ull;
-            const DNode nd = resident ? sl.nodes[base + static_cast<uint32_t>(j)] : node_from_lane(ch, 8 * j);
-            bool h = ((gm >> lane) & 1ull) != 0ull;
-            if (ANY) h = h && !occluded;
-            RT_PROF_ADD(lane, 74, __popcll(__ballot(h)));
+        // the survivors, two at a time: the per-ray tests of two children are independent chains (content slab test, verified slab test of the
+        // reference's box) that the wave runs interleaved -- a lone wave waits out every dependent instruction of a single chain
+        const bool gl = ((gm >> lane) & 1ull) != 0ull && !(ANY && occluded);
+        auto ray_test = [&](const DNode &nd) -> bool {
+            bool h = gl;
             if (nd.pad[1] == 0u) {   // per-ray content test (as packet_walk): no countable point of the ray inside the subtree's content box
                 const float t0x = (nd.clo[0] - R.slab_pad - ox) * R.idx, t1x = (nd.chi[0] + R.slab_pad - ox) * R.idx;
                 const float t0y = (nd.clo[1] - R.slab_pad - oy) * R.idy, t1y = (nd.chi[1] + R.slab_pad - oy) * R.idy;
@@ -1469,23 +1617,35 @@ __device__ __forceinline__ void cone_walk(const DNode *__restrict__ nodes, const
                 const bool miss = (tin > tout) || (tout < -1e-3f) ||
                                   (ANY ? (tin > 0.981f) : (tin > best_t + 1e-3f * (1.0f + fabsf(best_t))));
                 h = h && !miss;
-                if (__ballot(h) == 0ull) continue;
             }
-            h = h && box_hit_verified(nd.bmin, ox, oy, oz, bx, by, bz, brx, bry, brz);     // BoundingBox::boxIntersect, exact
-            RT_PROF_ADD(lane, 4, 1);
-            const unsigned long long hm = __ballot(h);
-            if (hm == 0ull) continue;
+            return h && box_hit_verified(nd.bmin, ox, oy, oz, bx, by, bz, brx, bry, brz);     // BoundingBox::boxIntersect, exact
+        };
+        auto enter = [&](const DNode &nd, const uint32_t cj, const unsigned long long hm) {
+            if (hm == 0ull) return;
             RT_PROF_ADD(lane, 91, 1); RT_PROF_ADD(lane, 75, __popcll(hm));
-            const uint32_t cj = base + static_cast<uint32_t>(j);
             if (nd.count_flags & RT_NODE_LEAF) {
-                if ((nd.count_flags & 0x7fffffffu) == 0u) continue;
-                if (lane == 0) { sl.lnode[nleaf] = cj; sl.lmask[nleaf] = hm; }      // (at most 8 per group; the list is emptied before the next group)
+                if ((nd.count_flags & 0x7fffffffu) == 0u) return;
+                if (lane == 0) { sl.lnode[nleaf] = cj; sl.lmask[nleaf] = hm; cl.lcb[nleaf] = 0xffffffffu; cl.lce[nleaf] = 0xffffffffu; }      // (at most 8 per group; the list is emptied before the next group)
                 ++nleaf;
             } else {
-                if ((nd.count_flags & 0xfu) == 0u) continue;              // a "lost" node: no children
+                if ((nd.count_flags & 0xfu) == 0u) return;               // a "lost" node: no children
                 if (lane == 0) { stk.node[sp] = nd.first | ((nd.count_flags & 0xfu) << 28); stk.mask[sp] = hm; }
                 ++sp;
             }
+        };
+        while (surv != 0ull) {
+            const int j0 = static_cast<int>(__builtin_ctzll(surv));
+            surv &= surv - 1ull;
+            const bool two = surv != 0ull;
+            const int j1 = two ? static_cast<int>(__builtin_ctzll(surv)) : j0;
+            if (two) surv &= surv - 1ull;
+            const DNode na = resident ? sl.nodes[base + static_cast<uint32_t>(j0)] : node_from_lane(ch, 8 * j0);
+            const DNode nb = resident ? sl.nodes[base + static_cast<uint32_t>(j1)] : node_from_lane(ch, 8 * j1);
+            RT_PROF_ADD(lane, 74, (two ? 2 : 1) * __popcll(__ballot(gl))); RT_PROF_ADD(lane, 4, two ? 2 : 1);
+            const bool ha = ray_test(na), hb = ray_test(nb);
+            const unsigned long long hma = __ballot(ha), hmb = two ? __ballot(hb) : 0ull;
+            enter(na, base + static_cast<uint32_t>(j0), hma);
+            enter(nb, base + static_cast<uint32_t>(j1), hmb);
         }
     }
     RT_PH(wc, 0);
@@ -1805,13 +1965,18 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
                                                           Control *__restrict__ ctl, float4 *__restrict__ rec,
                                                           int32_t *__restrict__ out_hit, float *__restrict__ out_t,
                                                           unsigned long long *best, unsigned long long *lit, const TaskQueues Q) {
-    // GROUP: the walking launches of the two traversal stages (fast variants) take the cone walk -- groups of children in one round trip,
-    // the top of the tree in LDS -- and need no triangle staging buffer (leaf_visit<.., STAGED = false>); the counting variants and the
-    // leaf-task launches keep the stack walk.
-#ifdef RT_NO_GROUP_WALK
-    constexpr bool GROUP = false;                 // A/B build (make ab): the stack walk everywhere
+    // GROUP (build flag -DRT_GROUP_WALK, default OFF): the two traversal stages of the fast variants take the cone walk above -- groups of
+    // children in one round trip, the top of the tree in LDS, common-origin cone tests, one task reservation per unit -- instead of the
+    // stack walk.  Measured A/B on one box (round 3, tools/r3_env.sh; trace group per frame): dodgeColorTest.obj 1080p 0.305-0.316 ms against
+    // 0.259-0.268 ms for the stack walk, cfg4 3.92 ms (2.45 ms with RT_GROUP_BUDGET=4) against 2.18 ms.  The cone test removes 75 % of the
+    // per-ray child tests (29 k of 117 k children survive on dodge) but the launches are not bound by those: their duration IS their longest
+    // unit (per-unit records of the RT_UNIT_HIST build: 150 k / 260 k cycles for the two stages against a mean wave lifetime of 28 k / 16 k),
+    // a serial chain of ~10-16 node visits and 6-23 leaf visits that runs at 15-20 cycles per instruction in a wave of its own, and the cone
+    // walk's extra state (138 VGPRs: 3 waves per SIMD) makes that chain longer, not shorter.  What did help both walks is in Control::n_task_tr.
+#ifdef RT_GROUP_WALK
+    constexpr bool GROUP = !COUNT && STAGE < 2;
 #else
-    constexpr bool GROUP = !COUNT && !CONT && STAGE < 2;
+    constexpr bool GROUP = false;
 #endif
     constexpr bool CONE = GROUP || (CONT && STAGE < 2 && !COUNT);
     __shared__ uint4 s_stage[GROUP ? 1 : RT_WAVES * RT_STAGE_TRIS * 5];
@@ -1821,6 +1986,9 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
     __shared__ uint4 s_top[GROUP ? RT_LDS_NODES * 4 : 1];           // the top of the octree: first RT_LDS_NODES DNodes (breadth-first order)
     __shared__ unsigned long long s_lmask[GROUP ? RT_WAVES * RT_LEAF_SLOTS : 1];
     __shared__ uint32_t s_lnode[GROUP ? RT_WAVES * RT_LEAF_SLOTS : 1];
+    __shared__ uint32_t s_lcb[GROUP ? RT_WAVES * RT_LEAF_SLOTS : 1], s_lce[GROUP ? RT_WAVES * RT_LEAF_SLOTS : 1];
+    __shared__ unsigned long long s_pmask[GROUP ? RT_WAVES * RT_PEND_SLOTS : 1];
+    __shared__ uint32_t s_pnode[GROUP ? RT_WAVES * RT_PEND_SLOTS : 1], s_pinfo[GROUP ? RT_WAVES * RT_PEND_SLOTS : 1];
     __shared__ float4 s_shaft[GROUP ? RT_WAVES * 16 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const WaveStack stk{s_node + wave * RT_STACK, s_mask + wave * RT_STACK, s_stage + (GROUP ? 0 : wave * RT_STAGE_TRIS * 5)};
@@ -1848,7 +2016,9 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
                       , nullptr
 #endif
     };
-    (void)sl;
+    const ConeLds cl{s_pnode + (GROUP ? wave * RT_PEND_SLOTS : 0), s_pmask + (GROUP ? wave * RT_PEND_SLOTS : 0), s_pinfo + (GROUP ? wave * RT_PEND_SLOTS : 0),
+                     s_lcb + (GROUP ? wave * RT_LEAF_SLOTS : 0), s_lce + (GROUP ? wave * RT_LEAF_SLOTS : 0)};
+    (void)sl; (void)cl;
     const DNode root = nodes[0];
     DCam cam;
     if (PRIMARY) cam = *camp;
@@ -1877,6 +2047,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
         wc.dbg = s_dbg + wave * 8;
         if (lane == 0) for (int k = 0; k < 6; ++k) wc.dbg[k] = 0u;
 #endif
+        ConeTasks TQ{nullptr, nullptr, 0u, 0u, 1u, 0u, 0u, 0u, 0u, 0u, 0u, 0ull};
         if (CONT) {
             uint32_t tsh, tloc, tn;
             shard_find(tmap, work, tsh, tloc, tn);
@@ -1887,11 +2058,20 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
             wc.start_mask = uniform_u64(task.mask);
             wc.c_begin = uniform_u32(task.c_begin);
             wc.c_end = uniform_u32(task.c_end);
+            // (cone walk: a group entry or a chunk range of a leaf, for the rays of the task's mask; a task hands nothing on)
+            TQ.start_kind = uniform_u32(task.pad0) == 1u ? 1u : 2u;
+            TQ.start_node = wc.start_node; TQ.start_mask = wc.start_mask; TQ.start_cb = wc.c_begin; TQ.start_ce = wc.c_end;
+            if (GROUP) wc.resume = false;
         }
-        if (STAGE < 2 && Q.tasks_out != nullptr && Q.budget != 0u) {
+        if (STAGE < 2 && Q.tasks_out != nullptr && (Q.budget != 0u || Q.group_budget != 0u)) {
             const uint32_t tsh = blockIdx.x & (RT_LIST_SHARDS - 1u), tcap = Q.cap / RT_LIST_SHARDS;      // sharded task queue (Control::n_task_tr)
-            wc.budget = Q.budget; wc.unit = unit; wc.tasks = Q.tasks_out + tsh * tcap; wc.task_count = &ctl->n_task_tr[level][Q.q_out & 1u][tsh * 16u]; wc.task_cap = tcap;
-            wc.target = Q.target ? Q.target : Q.budget;
+            if (GROUP) {
+                TQ.tasks = Q.tasks_out + tsh * tcap; TQ.count = &ctl->n_task_tr[level][Q.q_out & 1u][tsh * 16u]; TQ.cap = tcap;
+                TQ.budget = Q.budget; TQ.target = Q.target ? Q.target : (Q.budget ? Q.budget : 1000u); TQ.group_budget = Q.group_budget; TQ.unit = unit;
+            } else {
+                wc.budget = Q.budget; wc.unit = unit; wc.tasks = Q.tasks_out + tsh * tcap; wc.task_count = &ctl->n_task_tr[level][Q.q_out & 1u][tsh * 16u]; wc.task_cap = tcap;
+                wc.target = Q.target ? Q.target : Q.budget;
+            }
         }
         const uint32_t tile = STAGE == 1 ? unit / static_cast<uint32_t>(lslots) : unit;
         const int l = STAGE == 1 ? static_cast<int>(unit - tile * static_cast<uint32_t>(lslots)) : 0;
@@ -1943,7 +2123,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
             if (GROUP) {
                 CC.node_ok = dirs_ok(in_root, bx, by, bz);
                 const RayLane R{r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, brx, bry, brz, 4e-4f * (fabsf(r.ox) + fabsf(r.oy) + fabsf(r.oz) + S.extent)};
-                cone_walk<false>(nodes, tris, chunks, leaf_chunk0, stk, sl, lane, wc, root, in_root, R, bx, by, bz, brx, bry, brz, CC, best_t, best_f, dummy);
+                cone_walk<false>(nodes, tris, chunks, leaf_chunk0, stk, sl, cl, lane, wc, TQ, root, in_root, R, bx, by, bz, brx, bry, brz, CC, best_t, best_f, dummy);
             } else {
                 packet_walk<false, COUNT>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, wc, in_root, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz,
                                           bx, by, bz, brx, bry, brz, best_t, best_f, dummy, c_box, c_ref, sig_unused);
@@ -1986,7 +2166,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_stage(const DNode *__restrict
                 if (GROUP) {
                     CC.node_ok = dirs_ok(sroot, sdx, sdy, sdz);
                     const RayLane R{px, py, pz, sdx, sdy, sdz, srx, sry, srz, 4e-4f * (fabsf(px) + fabsf(py) + fabsf(pz) + S.extent)};
-                    cone_walk<true>(nodes, tris, chunks, leaf_chunk0, stk, sl, lane, wc, root, sroot, R, sdx, sdy, sdz, srx, sry, srz, CC, t_unused, f_unused, occ);
+                    cone_walk<true>(nodes, tris, chunks, leaf_chunk0, stk, sl, cl, lane, wc, TQ, root, sroot, R, sdx, sdy, sdz, srx, sry, srz, CC, t_unused, f_unused, occ);
                 } else {
                     packet_walk<true, COUNT>(nodes, tris, chunks, leaf_chunk0, S.extent, stk, lane, wc, sroot, px, py, pz, sdx, sdy, sdz, sdx, sdy, sdz,
                                              srx, sry, srz, t_unused, f_unused, occ, c_box, c_ref, sig_unused);
