@@ -331,6 +331,28 @@ def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, c
     return rec
 
 
+class HostGatherComm:
+    """Stand-in for rt_comm in the gloo rehearsal of `bench.py --gpus N` on a one-GPU box: the same call shape as shard.Comm.gather_rows,
+    the exchange itself through host copies and torch.distributed.gather.  Only the exchange is replaced: buffers, events and the two-stream
+    pipeline of step_comm run as on the real path (the host copy waits for the gather stream, so render i + 1 does not overlap gather i)."""
+
+    def __init__(self, torch, dist, rank, world):
+        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+
+    def gather_rows(self, d_local_ptr, nbytes, d_gathered_ptr, root=0, stream_ptr=None, local=None, gathered=None, stream=None):
+        torch = self.torch
+        with torch.cuda.stream(stream):
+            src = local.cpu()                                   # (waits for everything queued on the gather stream, i.e. the `rendered` event)
+        bufs = [torch.empty_like(src) for _ in range(self.world)] if self.rank == root else None
+        self.dist.gather(src, gather_list=bufs, dst=root)
+        if self.rank == root:
+            with torch.cuda.stream(stream):
+                gathered.copy_(torch.cat(bufs), non_blocking=False)
+
+    def close(self):
+        pass
+
+
 def run_multi(pkg, torch, dist, dev, rank, world, backend, args):
     """N > 1: every rank renders its interleaved row stripes; the step is a hipGraph replay of the frame + ONE gather of the 8-bit rows to
     rank 0 through the library's own RCCL binding (rt_comm_gather_rows), double buffered so that render i+1 overlaps gather i."""
@@ -375,18 +397,29 @@ def run_multi(pkg, torch, dist, dev, rank, world, backend, args):
     reduce_(counters, dist.ReduceOp.SUM)
     tot = [int(x) for x in counters.tolist()]
 
-    # ---- the library's own communicator (RCCL, one per process/GPU); the unique id travels over torch.distributed
+    # ---- the library's own communicator (RCCL, one per process/GPU); the unique id travels over torch.distributed.
+    # Every rank issues the SAME collectives whatever fails locally: rank 0 makes the id in a try block of its own and always takes part in
+    # the broadcast (an `ok` byte rides along); the communicator is then built in a second try block and one all_reduce settles the path.
+    # (Mismatched NCCL collectives -- rank 0 skipping the broadcast after a failed rt_comm_unique_id -- hang instead of failing.)
     comm, step_kind = None, None
-    if not on_host and not args.eager:
-        try:
-            idt = torch.zeros(capi.RT_COMM_ID_BYTES, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(pkg.shard.Comm.unique_id()), dtype=torch.uint8))
-            dist.broadcast(idt, src=0)
-            comm = pkg.shard.Comm(dev.index, bytes(idt.cpu().numpy().tobytes()), world, rank)
-        except Exception as e:            # noqa: BLE001
-            print(f"[bench] rt_comm setup failed on rank {rank}: {e}; falling back to torch.distributed.gather", file=sys.stderr)
-            comm = None
+    if on_host and not args.eager:
+        comm = HostGatherComm(torch, dist, rank, world)          # gloo rehearsal: the pipelined step with a host-side stand-in for the exchange ONLY
+    elif not args.eager:
+        idt = torch.zeros(capi.RT_COMM_ID_BYTES + 1, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            try:
+                raw = bytearray(pkg.shard.Comm.unique_id()) + bytearray([1])
+                idt.copy_(torch.frombuffer(raw, dtype=torch.uint8))
+            except Exception as e:            # noqa: BLE001
+                print(f"[bench] rt_comm_unique_id failed on rank 0: {e}; every rank falls back to torch.distributed.gather", file=sys.stderr)
+        dist.broadcast(idt, src=0)
+        raw = bytes(idt.cpu().numpy().tobytes())
+        if raw[-1] == 1:
+            try:
+                comm = pkg.shard.Comm(dev.index, raw[:-1], world, rank)
+            except Exception as e:            # noqa: BLE001
+                print(f"[bench] rt_comm_create failed on rank {rank}: {e}; falling back to torch.distributed.gather", file=sys.stderr)
+                comm = None
     flag = torch.tensor([1.0 if comm else 0.0], dtype=torch.float64, device=dev)
     reduce_(flag, dist.ReduceOp.MIN)                    # every rank must take the same path
     if flag.item() < 0.5 and comm:
@@ -413,7 +446,10 @@ def run_multi(pkg, torch, dist, dev, rank, world, backend, args):
             render_eager(u8[b], _p(0))
         rendered[b].record(stream)
         gstream.wait_event(rendered[b])
-        comm.gather_rows(u8[b].data_ptr(), block, gathered[b].data_ptr() if rank == 0 else 0, 0, gstream.cuda_stream)
+        if isinstance(comm, HostGatherComm):
+            comm.gather_rows(0, block, 0, 0, None, local=u8[b], gathered=gathered[b], stream=gstream)
+        else:
+            comm.gather_rows(u8[b].data_ptr(), block, gathered[b].data_ptr() if rank == 0 else 0, 0, gstream.cuda_stream)
         gathered_ev[b].record(gstream)
 
     def step_torch(i):
@@ -423,7 +459,8 @@ def run_multi(pkg, torch, dist, dev, rank, world, backend, args):
         dist.gather(src, gather_list=bufs, dst=0)
 
     step = step_comm if comm else step_torch
-    step_kind = ("hipGraph replay" if graphs else "eager launches") + " + rt_comm_gather_rows (RCCL via the C ABI), double buffered" if comm \
+    exchange = "a HOST-side stand-in for the exchange (gloo rehearsal)" if isinstance(comm, HostGatherComm) else "rt_comm_gather_rows (RCCL via the C ABI)"
+    step_kind = ("hipGraph replay" if graphs else "eager launches") + f" + {exchange}, double buffered" if comm \
         else "eager launches + torch.distributed.gather"
     for i in range(max(4, args.warmup)):
         step(i)
@@ -443,10 +480,33 @@ def run_multi(pkg, torch, dist, dev, rank, world, backend, args):
     brk = capi.rt_stats()
     render_eager(u8[0], _p(0), brk)
     torch.cuda.synchronize(dev)
+    # ---- what every rank did: device ms of its share of the frame (one instrumented eager frame) and launches per frame
+    mine = torch.tensor([brk.ms_total, float(brk.launches_total)], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    if on_host:
+        hc = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(hc, mine.cpu())
+        every = hc
+    else:
+        dist.all_gather(every, mine)
+    per_rank = [{"rank": r, "device_ms_per_frame": round(float(e[0]), 4), "launches_per_frame": int(e[1])} for r, e in enumerate(every)]
+    # ---- the stitched frame of the last timed step against ONE ungathered render of the whole frame on rank 0
     check = None
     if rank == 0 and comm:
         full = pkg.shard.stitch_u8(gathered[(args.steps - 1) & 1].cpu().numpy(), block, W, H, S, world)
-        check = {"assembled_frame_sha256": hashlib.sha256(full.tobytes()).hexdigest(), "nonzero": bool(full.any())}
+        whole = torch.zeros(H * W * 3, dtype=torch.uint8, device=dev)
+        whole_rgb = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+        pw = pkg.make_params(W, H, D, 0, H, S, 0, 1)
+        st = lib.rt_render_device(ctx.handle, C.byref(cam), C.byref(L), C.byref(pw), C.c_void_p(whole_rgb.data_ptr()), C.c_void_p(whole.data_ptr()), None,
+                                  C.c_void_p(stream.cuda_stream), None)
+        capi.check(lib, ctx.handle, st, "rt_render_device (whole frame)")
+        torch.cuda.synchronize(dev)
+        want = whole.cpu().numpy().reshape(full.shape)
+        same = bool(np.array_equal(full, want))
+        check = {"assembled_frame_sha256": hashlib.sha256(full.tobytes()).hexdigest(), "ungathered_frame_sha256": hashlib.sha256(want.tobytes()).hexdigest(),
+                 "match": same, "nonzero": bool(full.any())}
+        if not same:
+            check["error"] = f"{int((full != want).sum())} bytes of the stitched frame differ from the plain render of the whole frame"
     if comm:
         comm.close()
     if rank != 0:
@@ -456,7 +516,7 @@ def run_multi(pkg, torch, dist, dev, rank, world, backend, args):
             "config": {"workload": f"{W}x{H} depth {D} {G * G}-sample area light, {scene_file}, 1 light, row stripes of {S} over {world} GPU(s)",
                        "width": W, "height": H, "max_depth": D, "samples": G * G, "scene": scene_file, "parallelism": f"rows{world}", "step": step_kind},
             "rays": {"primary": tot[1], "centre": tot[2], "sample": tot[3], "bounce": tot[4], "culled_pixels": tot[5]},
-            "gathered_frame": check,
+            "gathered_frame": check, "per_rank": per_rank,
             "roofline": {"bound": "valu", "kernel": "k_shadow", "achieved": None, "peak": VALU_PEAK_PER_SIMD_NS, "unit": "wave-instructions/SIMD/ns", "frac": None,
                          "traffic": None, "note": "the executed-work roofline is reported by the N = 1 run (same kernels, 1/N of the rows per rank)",
                          "timing_source": "one instrumented eager frame of rank 0 outside the timed region (HIP events)",
@@ -481,6 +541,8 @@ def main():
     ap.add_argument("--no-work-counters", action="store_true", help="skip the counting-build pass (PMC / rocprof runs: its launches carry the same kernel names)")
     ap.add_argument("--eager", action="store_true", help="N > 1: eager launches + torch.distributed.gather instead of graph replay + rt_comm gather")
     ap.add_argument("--cpu-stride", type=int, default=0, help="oracle pixel stride for the CPU baseline (0 = auto)")
+    ap.add_argument("--force-multi", action="store_true", help="N = 1: run the N > 1 step (graph replay + rt_comm gather over a one-rank RCCL communicator, "
+                    "double buffered) instead of the single-GPU loop -- the rehearsal of the multi-GPU code path on one GPU")
     args = ap.parse_args()
 
     import torch
@@ -503,7 +565,7 @@ def main():
 
     base = {"metric": "Mrays/s", "unit": "Mrays/s", "n_gpus": world, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic"}
-    if world == 1:
+    if world == 1 and not args.force_multi:
         default_call = args.scene == "cube" and (args.width, args.height, args.grid, args.depth) == (1920, 1080, 8, 4)
         rec = run_single(pkg, torch, dev, args.scene, args.width, args.height, args.grid, args.depth, args.stripe, args.steps, args.warmup,
                          not args.no_cpu_baseline, args.cpu_stride, True, not args.no_work_counters)
@@ -520,16 +582,22 @@ def main():
 
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
     if backend == "nccl":
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
     else:
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     rec = run_multi(pkg, torch, dist, dev, rank, world, backend, args)
+    bad = False
     if rank == 0:
         out = dict(base)
         out.update(rec)
         print(json.dumps(out), flush=True)
+        gf = rec.get("gathered_frame")
+        bad = bool(gf) and not gf.get("match", True)
     dist.destroy_process_group()
+    if bad:
+        raise SystemExit("bench.py: the frame stitched from the gathered rows differs from the plain render of the whole frame")
 
 
 if __name__ == "__main__":

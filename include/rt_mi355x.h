@@ -123,7 +123,8 @@ typedef struct rt_stats {
     uint64_t box_tests_shadow, leaf_tri_refs_shadow;   /* the share of the sample-shadow kernel (k_shadow)      */
     /* per-kernel device time of the last render, milliseconds (HIP events on the render stream)                 */
     float ms_trace, ms_shadow, ms_shade, ms_resolve, ms_total;
-    uint32_t launches_trace, launches_shadow, launches_shade;
+    uint32_t launches_trace, launches_shadow, launches_shade;   /* levels that launched the group (historic name)                 */
+    uint32_t launches_total;              /* device operations one frame enqueues: kernel launches + the control-block memset */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

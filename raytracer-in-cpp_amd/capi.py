@@ -68,7 +68,8 @@ class rt_stats(C.Structure):
                 ("box_tests_shadow", C.c_uint64), ("leaf_tri_refs_shadow", C.c_uint64),
                 ("ms_trace", C.c_float), ("ms_shadow", C.c_float), ("ms_shade", C.c_float),
                 ("ms_resolve", C.c_float), ("ms_total", C.c_float),
-                ("launches_trace", C.c_uint32), ("launches_shadow", C.c_uint32), ("launches_shade", C.c_uint32)]
+                ("launches_trace", C.c_uint32), ("launches_shadow", C.c_uint32), ("launches_shade", C.c_uint32),
+                ("launches_total", C.c_uint32)]
 
     def total_rays(self):
         """Rays as SURVEY.md §8(d) counts them: every traversal query, incl. the root-AABB-only culled pixels."""

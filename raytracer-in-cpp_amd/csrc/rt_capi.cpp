@@ -100,6 +100,7 @@ struct rt_ctx {
     hipEvent_t cam_events[512] = {};  // one per camera-ring slot: recorded after the slot's H2D copy, waited for before the slot is reused
     float *d_offsets = nullptr;  // RT_LIGHT_SPHERE sample offsets of the last eager call (a captured graph owns a copy of its own: rt_graph)
     size_t cap_offsets = 0;
+    uint32_t frame_launches = 0;               // device operations (kernel launches + memsets) the last run_frame enqueued
     hipStream_t last_frame_stream = nullptr;   // stream of the most recent eager frame (it may still read d_offsets)
     float *d_rgb = nullptr;      // staging for rt_render (host output)
     int32_t *d_hit = nullptr;
@@ -676,8 +677,10 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
     rt_status s = ensure_frame(c, F.npix, D + 1, P, tiles, static_cast<size_t>(lslots));
     if (s != RT_OK) return s;
     F.item_cap = F.ray_cap = list_cap(tiles);
+    uint32_t nl = 1;             // device operations of this frame: this memset + every kernel launch below
     HIPCHK(c, hipMemsetAsync(c->d_ctl, 0, kFrameClearBytes, st));        // everything but the sticky overflow word
     launch_set_prof(st, c->d_ctl, 0u);   // no-op unless built with -DRT_PROFILE
+    if (!primary) ++nl;
     if (!primary) HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&c->d_ctl->n_rays[0][0]), static_cast<int>(n_input_rays), 1, st));
     size_t ev = c->ev_base;
     if (cam) {   // (skipped when replaying a captured graph)
@@ -695,20 +698,20 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
         int32_t *hit_l = level == 0 ? d_hit : nullptr;
         float *t_l = level == 0 ? d_t : nullptr;
         if (c->flat || !c->staged_trace) {
-            launch_trace(prim, count, c->flat, tgrid, st, c->S, c->d_cam, L, F, level, 3 * level, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l, hit_l, t_l);
+            ++nl, launch_trace(prim, count, c->flat, tgrid, st, c->S, c->d_cam, L, F, level, 3 * level, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l, hit_l, t_l);
         } else {
             // tree scenes: closest hit -> light-centre visibility -> finish; each traversal stage writes its big leaves as
             // chunk-range tasks that a second launch spreads over all waves
             const uint32_t B = count ? 0u : c->trace_budget, cap = c->task_cap;
             for (int stage = 0; stage < 2; ++stage) {
                 const uint32_t q0 = static_cast<uint32_t>(stage);
-                launch_stage(prim, count, stage, false, tgrid * c->stage_mult, st, c->S, c->d_cam, L, F, level, lslots, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
+                ++nl, launch_stage(prim, count, stage, false, tgrid * c->stage_mult, st, c->S, c->d_cam, L, F, level, lslots, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
                              hit_l, t_l, c->d_best, c->d_lit, TaskQueues{nullptr, B ? c->d_tasks[stage] : nullptr, 0u, q0, cap, B, c->task_target, count ? 0u : c->group_budget});
                 if (B != 0u)
-                    launch_stage(prim, false, stage, true, tgrid, st, c->S, c->d_cam, L, F, level, lslots, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
+                    ++nl, launch_stage(prim, false, stage, true, tgrid, st, c->S, c->d_cam, L, F, level, lslots, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
                                  hit_l, t_l, c->d_best, c->d_lit, TaskQueues{c->d_tasks[stage], nullptr, q0, 0u, cap, 0u});
             }
-            launch_stage(prim, count, 2, false, tgrid, st, c->S, c->d_cam, L, F, level, lslots, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l, hit_l, t_l,
+            ++nl, launch_stage(prim, count, 2, false, tgrid, st, c->S, c->d_cam, L, F, level, lslots, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l, hit_l, t_l,
                          c->d_best, c->d_lit, TaskQueues{nullptr, nullptr, 0u, 0u, cap, 0u});
         }
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
@@ -721,30 +724,31 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
         // 0.60 ms of the former 0.77): 0.90 ms against 0.77.  cfg4: 9 % unblocked; the launch's own brake stops testing after 4k of 18k tiles.)
         const bool beam = !count && c->S.beam != 0 && (c->flat || c->beam_trees);
         const uint32_t *sidx = beam ? c->d_sidx : nullptr;
-        if (beam) launch_beam(c->cus * 4, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_sidx);
+        if (beam) ++nl, launch_beam(c->cus * 4, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_sidx);
         // tree scenes with one (hit, light) pair per wave: the shaft walk (rt_kernels.hip, k_shadow_shaft)
         const bool shaft = !c->flat && !count && c->S.shaft != 0 && L.n_samples >= c->shaft_min_samples;
         const uint32_t shaft_b = level == 0 ? c->shaft_budget : c->shaft_budget_deep;
         if (shaft)
-            launch_shadow_shaft(c->cus * c->occ_shaft, st, c->S, L, level, 3 * level + 1, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis,
+            ++nl, launch_shadow_shaft(c->cus * c->occ_shaft, st, c->S, L, level, 3 * level + 1, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis,
                                 c->d_tasks[0], c->task_cap, shaft_b, c->task_target, sidx);
         else
-            launch_shadow(count, c->flat, c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis,
+            ++nl, launch_shadow(count, c->flat, c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis,
                           c->d_tasks[0], c->task_cap, c->shadow_budget, c->task_target, sidx);
         if (shaft && shaft_b != 0u)
-            launch_shadow_shaft_cont(c->cus * c->occ_shaft, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[0], c->task_cap, sidx);
+            ++nl, launch_shadow_shaft_cont(c->cus * c->occ_shaft, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[0], c->task_cap, sidx);
         else if (!shaft && !c->flat && !count && c->shadow_budget != 0u)      // the big leaves of the shadow units, spread over all waves
-            launch_shadow_cont(c->cus * c->occ_shadow, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[0], nullptr, 2u, 0u,
+            ++nl, launch_shadow_cont(c->cus * c->occ_shadow, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_tasks[0], nullptr, 2u, 0u,
                                c->task_cap, 0u, sidx);
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));   // after the whole shadow group (incl. continuations)
         launch_set_prof(st, c->d_ctl, 0u);
-        launch_shade(c->cus * c->occ_shade, st, c->S, L, F, level, 3 * level + 2, lslots, c->d_items, c->d_ctl, c->d_vis, rec_l, fres_l, c->d_rays[(level + 1) & 1]);
+        ++nl, launch_shade(c->cus * c->occ_shade, st, c->S, L, F, level, 3 * level + 2, lslots, c->d_items, c->d_ctl, c->d_vis, rec_l, fres_l, c->d_rays[(level + 1) & 1]);
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));        // after k_shade (lean timing too: the shade interval is a single kernel)
     }
     DFrame Fr = F;
     Fr.max_depth = levels_run - 1;
-    launch_resolve(c->cus * 8, st, Fr, c->d_rec, c->d_fres, d_rgb, d_u8);
+    ++nl, launch_resolve(c->cus * 8, st, Fr, c->d_rec, c->d_fres, d_rgb, d_u8);
     if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
+    c->frame_launches = nl;
     HIPCHK(c, hipGetLastError());
     return RT_OK;
 }
@@ -769,6 +773,7 @@ static rt_status sum_frame_times(rt_ctx *c, size_t ev, int levels_run, rt_stats 
     out->launches_trace += static_cast<uint32_t>(levels_run);
     out->launches_shadow += static_cast<uint32_t>(levels_run);
     out->launches_shade += static_cast<uint32_t>(levels_run);
+    out->launches_total = c->frame_launches;
     return RT_OK;
 }
 
@@ -790,6 +795,7 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
     HIPCHK(c, hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
     { const rt_status os_ = check_overflow(c); if (os_ != RT_OK) return os_; }
     fold_stats(h);
+    out->launches_total = c->frame_launches;
     if (std::getenv("RT_DEBUG")) std::fprintf(stderr, "RT_DEBUG level0: items %u tasks closest %u %u centre %u %u shadow %u %u\n", [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_items[0][sh * 16]; return t; }(), [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_task_tr[0][0][sh * 16]; return t; }(), 0u, [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_task_tr[0][1][sh * 16]; return t; }(), 0u, [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_task_sh[0][sh * 16]; return t; }(), 0u);
     out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample;
     out->pixels = F.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;

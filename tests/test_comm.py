@@ -58,3 +58,44 @@ def test_render_gather_one_rank_equals_plain_render(rt):
     full = rt.shard.stitch_u8(gathered.cpu().numpy(), local.numel(), w, h, stripe, 1)
     assert np.array_equal(full.reshape(-1), ref.cpu().numpy())
     comm.close(); ctx.close(); hs.close()
+
+
+def _run_bench(args, env_extra=None, launcher=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    cmd = (launcher or [sys.executable]) + [os.path.join(root, "bench.py")] + args
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_step_runs_with_world_size_one_over_rccl():
+    """The N > 1 step of bench.py -- hipGraph replay on one stream, rt_comm_gather_rows (RCCL) on a second, two buffers, four events -- with a
+    ONE-rank communicator on one GPU (bench.py --force-multi): >= 8 timed steps, and the frame stitched from the gathered rows of the last
+    step equals the plain rt_render_device frame byte for byte (bench.py itself exits non-zero on a mismatch)."""
+    rec = _run_bench(["--gpus", "1", "--force-multi", "--steps", "9", "--warmup", "4", "--scene", "dodge", "--width", "640", "--height", "360"],
+                     {"MASTER_PORT": "29541"})
+    assert "rt_comm_gather_rows (RCCL via the C ABI)" in rec["config"]["step"] and "hipGraph replay" in rec["config"]["step"]
+    gf = rec["gathered_frame"]
+    assert gf["match"] and gf["nonzero"] and gf["assembled_frame_sha256"] == gf["ungathered_frame_sha256"]
+    assert rec["steps"] == 9 and rec["n_gpus"] == 1
+    pr = rec["per_rank"]
+    assert len(pr) == 1 and pr[0]["device_ms_per_frame"] > 0 and pr[0]["launches_per_frame"] >= 6
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_gloo_rehearsal_takes_the_pipelined_step():
+    """Two ranks on ONE GPU (RT_DIST_BACKEND=gloo): the same double-buffered step with a host-side stand-in for the exchange only; the
+    stitched frame of the two ranks' interleaved stripes equals the plain render of the whole frame."""
+    import sys
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29543"]
+    rec = _run_bench(["--gpus", "2", "--steps", "8", "--warmup", "4", "--scene", "cube", "--width", "480", "--height", "270"],
+                     {"RT_DIST_BACKEND": "gloo"}, launcher)
+    assert "stand-in" in rec["config"]["step"] and "double buffered" in rec["config"]["step"]
+    assert rec["gathered_frame"]["match"] and rec["n_gpus"] == 2
+    assert [p["rank"] for p in rec["per_rank"]] == [0, 1]
