@@ -46,6 +46,34 @@ __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {
     }
 }
 
+// Eigen's normalized() (Dot.h:124-134: v / sqrt(squaredNorm) when that is > 0) with the work the three IEEE divisions share done once.
+// hipcc expands a correctly rounded x / s into  d = div_scale(s), n = div_scale(x), r = rcp(d), e = fma(-d, r, 1), r = fma(e, r, r),
+// q = n r, q = fma(fma(-d, q, n), r, q), div_fmas(fma(-d, q, n), r, q), div_fixup  -- 11 instructions, of which the reciprocal and its
+// refinement depend on the divisor alone.  div_scale leaves both operands as they are and div_fmas / div_fixup pass the quotient through
+// whenever divisor and quotient are far from the ends of the exponent range, so for 2^-40 <= s <= 2^40 and 2^-60 <= |x| (<= s) the plain
+// FMA chain below IS that sequence, bit for bit, and the three quotients share r: 18 instead of 33 instructions.  Anything else -- a zero
+// or tiny component (the sign of a zero quotient comes from div_fixup), a huge or non-finite norm -- takes the three full divisions; the
+// test is wave-uniform, so the common case has no divergent branch.  (k_shade runs two of these per sample.)
+__device__ __forceinline__ void normalize3_shared(float &x, float &y, float &z) {
+    const float q = x * x + (y * y + z * z);
+    const float s = sqrtf(q);
+    const bool ok = (s >= 0x1p-40f) && (s <= 0x1p40f) && (fminf(fminf(fabsf(x), fabsf(y)), fabsf(z)) >= 0x1p-60f);     // NaN: false
+    if (__ballot(!ok) == 0ull) {
+        float r = __builtin_amdgcn_rcpf(s);
+        const float e = __builtin_fmaf(-s, r, 1.0f);
+        r = __builtin_fmaf(e, r, r);
+        float qx = x * r, qy = y * r, qz = z * r;
+        qx = __builtin_fmaf(__builtin_fmaf(-s, qx, x), r, qx);
+        qy = __builtin_fmaf(__builtin_fmaf(-s, qy, y), r, qy);
+        qz = __builtin_fmaf(__builtin_fmaf(-s, qz, z), r, qz);
+        x = __builtin_fmaf(__builtin_fmaf(-s, qx, x), r, qx);
+        y = __builtin_fmaf(__builtin_fmaf(-s, qy, y), r, qy);
+        z = __builtin_fmaf(__builtin_fmaf(-s, qz, z), r, qz);
+    } else if (q > 0.0f) {
+        x = x / s; y = y / s; z = z / s;
+    }
+}
+
 __device__ __forceinline__ uint32_t uniform_u32(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
@@ -3160,6 +3188,12 @@ __device__ const unsigned long long POWF_EXP2_TAB[32] = {
     0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
     0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
 
+// The polynomial coefficients and thresholds of e_powf.c, kept behind the tables in LDS ([64, 76)): as literals every one of them is
+// re-materialised with two v_mov per use inside the sample loop (no 64-bit literal operands on this ISA) -- a sixth of the loop's VALU
+// slots; as LDS words they are broadcast ds_read_b64, which do not take a VALU slot.
+__device__ const double POWF_CONST[12] = {0x1.27616c9496e0bp-2, -0x1.71969a075c67ap-2, 0x1.ec70a6ca7baddp-2, -0x1.7154748bef6c8p-1, 0x1.71547652ab82bp+0,
+                                          0x1.fffffffd1d571p+6, -150.0, -149.0, 0x1.8p+47, 0x1.c6af84b912394p-5, 0x1.ebfce50fac4f3p-3, 0x1.62e42ff0c52d6p-1};
+#define RT_POW_TAB 76
 // The tables live in LDS for the kernel (64 x 8 B: INVC[16] | LOGC[16] | EXP2_TAB[32]): a lookup is a ds_read_b64, not a global load on the
 // critical path of every sample.  The function has NO divergent branch: the one common special case (cosphi = +0 with a positive finite
 // shininess: the answer is +0) and the three range answers of the main path are selects; everything else e_powf.c answers without
@@ -3208,28 +3242,29 @@ __device__ __forceinline__ float pow_shininess(const float x, const float y, con
     const double r = __builtin_fma(z, tab[i], -1.0);
     const double y0 = tab[16u + i] + static_cast<double>(k);
     const double r2 = r * r;
-    const double yy = __builtin_fma(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
-    const double p = __builtin_fma(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
+    const double yy = __builtin_fma(tab[64], r, tab[65]);
+    const double p = __builtin_fma(tab[66], r, tab[67]);
     const double r4 = r2 * r2;
-    double q = __builtin_fma(0x1.71547652ab82bp+0, r, y0);
+    double q = __builtin_fma(tab[68], r, y0);
     q = __builtin_fma(p, r2, q);
     const double logx = __builtin_fma(yy, r4, q);
     const double ylogx = static_cast<double>(y) * logx;
     // |y * log2(x)| >= 126: __math_oflowf / __math_uflowf / __math_may_uflowf, else the ordinary path (also for -149 <= y log2 x <= -126)
     const bool big = ((static_cast<unsigned long long>(__double_as_longlong(ylogx)) >> 47) & 0xffffull) >= 0x80bfull;
-    const bool r_of = big && (ylogx > 0x1.fffffffd1d571p+6);
-    const bool r_uf = big && !r_of && (ylogx <= -150.0);
-    const bool r_mu = big && !r_of && !r_uf && (ylogx < -149.0);
+    const bool r_of = big && (ylogx > tab[69]);
+    const bool r_uf = big && !r_of && (ylogx <= tab[70]);
+    const bool r_mu = big && !r_of && !r_uf && (ylogx < tab[71]);
     // exp2_inline
-    double kd = ylogx + 0x1.8p+47;
+    const double shift = tab[72];
+    double kd = ylogx + shift;
     const unsigned long long ki = static_cast<unsigned long long>(__double_as_longlong(kd));
-    kd -= 0x1.8p+47;
+    kd -= shift;
     const double rr = ylogx - kd;
     const unsigned long long t = static_cast<unsigned long long>(__double_as_longlong(tab[32u + static_cast<uint32_t>(ki & 31ull)])) + (ki << 47);
     const double sc = __longlong_as_double(static_cast<long long>(t));
-    const double zz = __builtin_fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
+    const double zz = __builtin_fma(tab[73], rr, tab[74]);
     const double rr2 = rr * rr;
-    double yv = __builtin_fma(0x1.62e42ff0c52d6p-1, rr, 1.0);
+    double yv = __builtin_fma(tab[75], rr, 1.0);
     yv = __builtin_fma(zz, rr2, yv);
     yv = yv * sc;
     float res = static_cast<float>(yv);
@@ -3256,14 +3291,17 @@ __device__ __forceinline__ float fresnel_term(float ix, float iy, float iz, floa
 #define RT_SHADE_WPE 4
 #endif
 #define RT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(RT_SHADE_WPE, 8)))
+// SIMPLE: the light is a point or a grid of at most 64 samples (one visibility word per (hit, light), sample s = bit s, no 8 x 8 blocks, no
+// sphere offsets) -- the reference's own 5 x 5 and the 8 x 8 headline.  The sample loop then carries no word / block / mode branches.
+template <bool SIMPLE>
 __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, const DLights L, const DFrame F, const int level, const int ctr_slot,
                                                const int lslots, const ShadeItem *__restrict__ items, Control *__restrict__ ctl,
                                                const unsigned long long *__restrict__ vis, float4 *__restrict__ rec,
                                                float *__restrict__ fres, RayItem *__restrict__ rays_out) {
-    __shared__ double s_pow[64];               // powf tables: INVC[16] | LOGC[16] | EXP2_TAB[32] (bit patterns)
-    if (threadIdx.x < 64u) {
+    __shared__ double s_pow[RT_POW_TAB];       // powf tables: INVC[16] | LOGC[16] | EXP2_TAB[32] (bit patterns) | coefficients and thresholds [12]
+    if (threadIdx.x < RT_POW_TAB) {
         const uint32_t ti = threadIdx.x;
-        s_pow[ti] = ti < 16u ? POWF_LOG2_INVC[ti] : (ti < 32u ? POWF_LOG2_LOGC[ti - 16u] : __longlong_as_double(static_cast<long long>(POWF_EXP2_TAB[ti - 32u])));
+        s_pow[ti] = ti < 16u ? POWF_LOG2_INVC[ti] : (ti < 32u ? POWF_LOG2_LOGC[ti - 16u] : (ti < 64u ? __longlong_as_double(static_cast<long long>(POWF_EXP2_TAB[ti - 32u])) : POWF_CONST[ti - 64u]));
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -3334,30 +3372,33 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
                 const LightGrid lg = light_grid(L, px, py, pz);
                 uint32_t si = 0, sj = 0;                       // s = si * vsteps + sj, kept as counters: no division per sample
                 const uint32_t vst = static_cast<uint32_t>(L.vsteps > 0 ? L.vsteps : 1);
-                const bool blocks = sample_blocks(L);
+                const bool blocks = !SIMPLE && sample_blocks(L);
                 const uint32_t bpr = vst >> 3;
+                if (SIMPLE) word = vw[0];
 #pragma unroll 2
                 for (uint32_t s = 0; s < N; ++s) {
                     uint32_t bit = s & 63u;
-                    if (blocks) {
-                        if ((sj & 7u) == 0u) word = vw[(si >> 3) * bpr + (sj >> 3)];       // a new block every 8 samples of a grid row
-                        bit = ((si & 7u) << 3) | (sj & 7u);
-                    } else if (bit == 0u) {
-                        word = vw[s >> 6];
+                    if (!SIMPLE) {
+                        if (blocks) {
+                            if ((sj & 7u) == 0u) word = vw[(si >> 3) * bpr + (sj >> 3)];       // a new block every 8 samples of a grid row
+                            bit = ((si & 7u) << 3) | (sj & 7u);
+                        } else if (bit == 0u) {
+                            word = vw[s >> 6];
+                        }
                     }
                     const bool visible = ((word >> bit) & 1ull) != 0ull;
                     sum += visible ? 1.0f : 0.0f;
                     float sx, sy, sz;
                     grid_sample(lg, static_cast<float>(si) + 0.5f, static_cast<float>(sj) + 0.5f, sx, sy, sz);
-                    if (L.mode == RT_LIGHT_SPHERE) sphere_sample(L, s, px, py, pz, sx, sy, sz);
+                    if (!SIMPLE && L.mode == RT_LIGHT_SPHERE) sphere_sample(L, s, px, py, pz, sx, sy, sz);
                     if (++sj == vst) { sj = 0; ++si; }
                     float ldx = sx - hx, ldy = sy - hy, ldz = sz - hz;
-                    normalize3(ldx, ldy, ldz);
+                    normalize3_shared(ldx, ldy, ldz);
                     const float ldn = dot3(ldx, ldy, ldz, nx, ny, nz);
                     const float costheta = smax(0.0f, ldn);
                     const float two = 2 * ldn;
                     float rx = ldx - two * nx, ry = ldy - two * ny, rz = ldz - two * nz;
-                    normalize3(rx, ry, rz);
+                    normalize3_shared(rx, ry, rz);
                     const float cosphi = smax(0.0f, dot3(ex, ey, ez, -1.0f * rx, -1.0f * ry, -1.0f * rz));
                     const float pw = pow_shininess(cosphi, mat.shininess, s_pow);
                     const float tr_ = lkd0 * costheta + lks0 * pw, tg_ = lkd1 * costheta + lks1 * pw, tb_ = lkd2 * costheta + lks2 * pw;
@@ -3574,7 +3615,7 @@ void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow
         *shadow = q(k_shadow<false, false, false>, RT_WAVES * 64, 4);
         *shaft_out = q((k_shadow_shaft<false, false>), RT_WAVES * 64, 4);      // (its grid used to be the smaller of the two residencies: 4 of its 6 waves per SIMD)
     }
-    *shade = q(k_shade, 256, 2);
+    *shade = q(k_shade<true>, 256, 2);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -3664,7 +3705,10 @@ void launch_beam(int grid, hipStream_t st, const DScene &S, const DLights &L, in
 
 void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level, int slot, int lslots,
                   const ShadeItem *items, Control *ctl, const unsigned long long *vis, float4 *rec, float *fres, RayItem *rays_out) {
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(256), 0, st, S, L, F, level, slot, lslots, items, ctl, vis, rec, fres, rays_out);
+    if (L.mode != RT_LIGHT_SPHERE && L.n_samples <= 64)
+        hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(256), 0, st, S, L, F, level, slot, lslots, items, ctl, vis, rec, fres, rays_out);
+    else
+        hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(256), 0, st, S, L, F, level, slot, lslots, items, ctl, vis, rec, fres, rays_out);
 }
 
 void launch_resolve(int grid, hipStream_t st, const DFrame &F, const float4 *rec, const float *fres, float *out_rgb, uint8_t *out_u8) {
