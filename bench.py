@@ -41,7 +41,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-VALU_PEAK_PER_SIMD_NS = 0.967   # measured: tools/micro/valu_rate.hip (plain FP32 wave64 ops, 8 waves/SIMD)
+VALU_PEAK_PER_SIMD_NS = 0.967   # measured: tools/micro/valu_rate.hip (plain FP32 wave64 ops, 8 waves/SIMD); 0.5 per cycle, i.e. the chip held ~1.93 GHz in that run
 N_SIMDS = 1024                  # 256 CUs x 4 SIMDs
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 BOX_BYTES, TRI_REF_BYTES = 24, 52   # algorithmic bytes per box test / per leaf triangle reference
@@ -62,6 +62,7 @@ COST = {
     "unit_shaft": 270,           # k_shadow_shaft per unit: queue, item, sample, root test, shaft planes (make_shaft_lanes ~95), LDS records
     "unit_flat": 355,            # flat k_shadow per unit: queue, item, h, shaft planes (~85), 8 triangles x 8 tests per step (2 x ~45 on the cube), plane rule, visibility word
     "unit_stack": 200,
+    "unit_trace": 260,           # trace kernels per unit (a tile of 64 rays, or a leaf task): ray generation (Camera::screenToWorld in double), root tests, records / compaction
     "beam": 700,                 # k_beam per (tile of 64 hits, light) on a flat scene: items, wave min / max, planes, one leaf (chunk test + per-triangle test)
     "shade_sample": 215,         # k_shade per (tile of 64 hits, sample): light direction + reflection normalised (2 x sqrt + 6 IEEE divisions), glibc powf in double (branch-free: range and special answers are selects)
     "shade_tile": 500,           # k_shade per tile: items, interpolated normal, eye vector, material, record
@@ -108,10 +109,23 @@ def work_counters(pkg, hs, W, H, G, D):
         lib.rt_destroy(ctx)
     s = a[RT_WORK_SHADOW:RT_WORK_SHADOW + 96]
     t = a[0:96]
+    # Control::prof[RT_WORK_SHADOW + k]: step counters of the shadow kernels (k_beam, k_shadow, k_shadow_shaft and their leaf-task launches)
     names = {0: "tri_steps_lanes_rays", 2: "tri_steps_lanes_triangles", 4: "box_steps_stack_walk", 12: "chunk_tests_stack_walk", 13: "units",
              88: "shaft_groups", 90: "nodes_tested_per_ray", 91: "nodes_hit", 92: "leaf_chunk_batches", 94: "chunks_tested_per_ray", 95: "chunks_with_work",
              70: "tri_shaft_tests", 71: "tri_shaft_survivors", 72: "tri_shaft_rays", 73: "tri_shaft_empty_chunks", 74: "node_test_live_rays", 75: "node_hit_rays", 76: "beams_tested", 77: "beams_unblocked", 78: "beam_hits_checked_per_leaf_list", 79: "beam_hits_that_reach_a_bad_leaf", 80: "beam_steps_of_unblocked", 81: "beams_over_budget"}
-    return {"shadow": {v: s[k] for k, v in names.items()}, "trace": {v: t[k] for k, v in names.items()}}
+    # Control::prof[k]: step counters of the trace kernels (k_trace / k_stage and the leaf-task launches of the two traversal stages).  They share
+    # the leaf code (leaf_visit) with the shadow kernels but none of the shaft / beam steps, so the region has names of its own.
+    trace_names = {0: "tri_steps_lanes_rays", 2: "tri_steps_lanes_triangles", 4: "box_steps_stack_walk", 6: "leaves_lanes_rays", 7: "leaves_lanes_triangles",
+                   12: "chunk_tests_stack_walk", 13: "units", 14: "ray_chunk_pairs_culled", 66: "ray_node_pairs_content_culled",
+                   70: "tri_cone_tests", 71: "tri_cone_survivors", 73: "tri_cone_empty_chunks"}
+    return {"shadow": {v: s[k] for k, v in names.items()}, "trace": {v: t[k] for k, v in trace_names.items()}}
+
+
+def trace_model(work, flat):
+    """modelled VALU wave-instructions of the trace group (closest hit + light-centre visibility + finish): (useful, total)"""
+    w = work["trace"]
+    useful = w["tri_steps_lanes_triangles"] * COST["tri_lanes_triangles"] + w["tri_steps_lanes_rays"] * COST["tri_lanes_rays"] + w["box_steps_stack_walk"] * COST["box_stack_walk"]
+    return useful, useful + w["units"] * COST["unit_trace"] + w["chunk_tests_stack_walk"] * 30 + w["tri_cone_tests"] * COST["tri_shaft_test"]
 
 
 def valu_model(work, flat, shaft):
@@ -129,6 +143,26 @@ def valu_model(work, flat, shaft):
         return useful, total
     useful += w["box_steps_stack_walk"] * COST["box_stack_walk"]
     return useful, useful + w["units"] * COST["unit_stack"] + w["chunk_tests_stack_walk"] * 30
+
+
+def clock_independent(kernels, pick):
+    """SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8) / 1024 SIMDs / 0.5 wave-instructions per cycle, launch by launch (profiles/valu.json): the share of
+    the VALU issue peak the launches reached WHATEVER clock the chip held (the per-ns figures above divide by a rate measured at ~1.93 GHz).
+    With the second PMC pass: SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES-style busy shares where the counters were collected."""
+    sel = {k: v for k, v in kernels.items() if pick(k) and v.get("gpu_cycles")}
+    if not sel:
+        return {}
+    insts = sum(v["valu_wave_instructions"] for v in sel.values())
+    cyc = sum(v["gpu_cycles"] for v in sel.values())
+    out = {"frac_clock_independent": round(insts / cyc / N_SIMDS / 0.5, 4),
+           "clock_independent_source": "sum SQ_INSTS_VALU / sum (GRBM_GUI_ACTIVE / 8) / 1024 SIMDs / 0.5 per cycle over the level-0 launches of the group"}
+    act = [v for v in sel.values() if v.get("active_inst_valu") and v.get("busy_cycles")]
+    if act:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles in which a wave executes a VALU instruction, SQ_BUSY_CYCLES the quad-cycles the SQs are busy (per SE): their
+        # ratio over the number of waves per SIMD that can issue is the time share of VALU execution -- double-rate FP64 work shows up here, not in the count
+        out["valu_active_over_busy"] = round(sum(v["active_inst_valu"] for v in act) / sum(v["busy_cycles"] for v in act), 4)
+        out["valu_active_source"] = "SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES (second rocprofv3 --pmc pass of tools/valu.sh)"
+    return out
 
 
 def pmc_constant(fname, scene, cfg, sha):
@@ -227,6 +261,7 @@ def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, c
         r = insts / (ms_shadow_frame * 1e6) / N_SIMDS
         roof["executed_valu"] = {"constant": True, "wave_instructions_per_frame_level0": int(insts), "per_simd_per_ns": round(r, 4),
                                  "frac": round(r / VALU_PEAK_PER_SIMD_NS, 4), "source": ent["how"]}
+        roof["executed_valu"].update(clock_independent(ent["kernels"], lambda k: "k_shadow" in k))
     else:
         roof["executed_valu"] = {"constant": True, "frac": None, "why": why}
     ent, why = pmc_constant("traffic.json", scene, cfg, sha)
@@ -260,18 +295,47 @@ def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, c
              "work": {"shade": {"tiles_of_64_hits": int(tiles), "samples": G * G}}, "cost_per_step": COST,
              "traffic": None, "hbm_frac": None, "timing_source": roof["timing_source"] if "timing_source" in roof else ""}
     ent, why = pmc_constant("valu.json", scene, cfg, sha)
-    if ent and "rtamd::k_shade" in ent["kernels"]:
-        insts = ent["kernels"]["rtamd::k_shade"]["valu_wave_instructions"]
+    if ent and any("k_shade" in k for k in ent["kernels"]):
+        insts = sum(v["valu_wave_instructions"] for k, v in ent["kernels"].items() if "k_shade" in k)
         r = insts / t_ns / N_SIMDS
         shade["executed_valu"] = {"constant": True, "wave_instructions_per_frame_level0": int(insts), "per_simd_per_ns": round(r, 4),
                                   "frac": round(r / VALU_PEAK_PER_SIMD_NS, 4), "source": ent["how"]}
+        shade["executed_valu"].update(clock_independent(ent["kernels"], lambda k: "k_shade" in k))
     else:
         shade["executed_valu"] = {"constant": True, "frac": None, "why": why or "no k_shade entry"}
-    roof["ms_per_frame"] = {"shadow": round(ms_shadow_frame, 4), "shade": round(ms_shade_frame, 4), "device_total": round(tim.ms_total / K_t, 4),
+    roof["ms_per_frame"] = {"trace": round(tim.ms_trace / K_t, 4), "shadow": round(ms_shadow_frame, 4), "shade": round(ms_shade_frame, 4), "device_total": round(tim.ms_total / K_t, 4),
                             "instrumented_frame": {"trace": round(brk.ms_trace, 4), "shadow": round(brk.ms_shadow, 4), "shade": round(brk.ms_shade, 4),
                                                    "resolve": round(brk.ms_resolve, 4), "total": round(brk.ms_total, 4)}}
 
+    # ---- the trace group (closest hit + light-centre visibility + finish), same model
+    ms_trace_frame = tim.ms_trace / K_t
+    trace = {"bound": "valu", "group": "trace", "kernel": "k_trace (flat scenes) / k_stage x 3 + the leaf-task launches of the two traversal stages (tree scenes)",
+             "unit": "wave-instructions/SIMD/ns", "peak": VALU_PEAK_PER_SIMD_NS, "peak_source": roof["peak_source"], "cost_per_step": COST,
+             "traffic": None, "hbm_frac": None, "timing_source": roof["timing_source"]}
+    if work:
+        tr_useful, tr_total = trace_model(work, flat)
+        t_ns = max(ms_trace_frame, 1e-6) * 1e6
+        trace.update({"achieved": round(tr_total / t_ns / N_SIMDS, 4), "frac": round(tr_total / t_ns / N_SIMDS / VALU_PEAK_PER_SIMD_NS, 4),
+                      "useful_frac": round(tr_useful / t_ns / N_SIMDS / VALU_PEAK_PER_SIMD_NS, 4),
+                      "modelled_valu_wave_instructions_per_frame": {"useful": int(tr_useful), "total": int(tr_total)}, "work": {"trace": work["trace"]}})
+    else:
+        trace.update({"achieved": None, "frac": None})
+    ent, why = pmc_constant("valu.json", scene, cfg, sha)
+    if ent:
+        sel = lambda k: "k_trace" in k or "k_stage" in k       # noqa: E731
+        insts = sum(v["valu_wave_instructions"] for k, v in ent["kernels"].items() if sel(k))
+        r = insts / (max(ms_trace_frame, 1e-6) * 1e6) / N_SIMDS
+        trace["executed_valu"] = {"constant": True, "wave_instructions_per_frame_level0": int(insts), "per_simd_per_ns": round(r, 4),
+                                  "frac": round(r / VALU_PEAK_PER_SIMD_NS, 4), "source": ent["how"]}
+        trace["executed_valu"].update(clock_independent(ent["kernels"], sel))
+    else:
+        trace["executed_valu"] = {"constant": True, "frac": None, "why": why}
+    # rays actually FORMED and walked: the frame's queries minus the sample segments whole tiles (k_beam) or whole (hit, light) units were proven
+    # unblocked for before a ray existed.  `value` counts queries resolved; this is the traversal count behind it.
+    rays_walked = int(cnt.rays_primary + cnt.rays_bounce + cnt.rays_centre + brk.rays_sample_walked)      # (brk: the instrumented frame of the shipped kernels)
+
     rec = {"value": round(value, 2), "ms_per_step": round(ms_step, 4), "steps": steps, "warmup": warmup, "rays_per_frame": rays_frame,
+           "rays_walked_per_frame": rays_walked, "Mrays_walked_per_s": round(rays_walked * steps / elapsed / 1e6, 2), "launches_per_frame": int(brk.launches_total),
            "config": {"workload": f"{W}x{H} depth {D} {G * G}-sample area light, {scene_file}, 1 light, row stripes of {S} over 1 GPU(s)",
                       "width": W, "height": H, "max_depth": D, "samples": G * G, "scene": scene_file, "parallelism": "rows1", "step": "eager launches",
                       "tree": {k: info[k] for k in ("nodes", "leaves", "face_refs", "max_leaf", "depth")}},
@@ -279,6 +343,8 @@ def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, c
            "roofline": roof}
     shade["ms_per_frame"] = roof["ms_per_frame"]
     shade["timing_source"] = roof["timing_source"]
+    trace["ms_per_frame"] = roof["ms_per_frame"]
+    rec["roofline_trace"] = trace
     # `roofline` is the group that takes most of the frame; the other one stays beside it
     if ms_shade_frame > ms_shadow_frame:
         rec["roofline"], rec["roofline_shadow"] = shade, roof
@@ -325,6 +391,14 @@ def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, c
                       "which measured 0.165-2.6 Mrays/s on 7 threads (BASELINE.md)",
             "seconds": round(sec, 3)}
         rec["speedup_vs_cpu_port"] = round(value / (cpu_rays / sec / 1e6), 1)
+        # the UNMODIFIED reference as the survey session measured it (another host -- 8-vCPU Xeon, 7 threads, -O2 -- at its own 25 samples on the
+        # 1440 x 1440 twin of this pixel count); it cannot be built here without a GL stand-in, so this ratio crosses hosts and sample counts and is quoted as such
+        ref_measured = {"cube": 2.6, "dodge": 0.165}.get(scene)
+        rec["cpu_baseline"]["ratios"] = {
+            "vs_port_same_host": {"value": rec["speedup_vs_cpu_port"], "cpu": f"oracle port, {threads} threads, this host"},
+            "vs_reference_as_surveyed": ({"value": round(value / ref_measured, 1), "cpu_Mrays_per_s": ref_measured,
+                                          "cpu": "unmodified reference, 7 threads of an 8-vCPU Xeon 2.1 GHz (BASELINE.md section 2), 1440x1440, 25 samples -- another host, another sample count"}
+                                         if ref_measured else None)}
         osc.close()
     ctx.close()
     hs.close()

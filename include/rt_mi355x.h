@@ -125,6 +125,8 @@ typedef struct rt_stats {
     float ms_trace, ms_shadow, ms_shade, ms_resolve, ms_total;
     uint32_t launches_trace, launches_shadow, launches_shade;   /* levels that launched the group (historic name)                 */
     uint32_t launches_total;              /* device operations one frame enqueues: kernel launches + the control-block memset */
+    uint64_t rays_sample_walked;          /* sample shadow segments actually FORMED and walked: rays_sample minus those whole tiles (k_beam) or whole
+                                             (hit, light) units were proven unblocked for before a ray existed (0 in the counting pass)  */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

@@ -69,7 +69,7 @@ class rt_stats(C.Structure):
                 ("ms_trace", C.c_float), ("ms_shadow", C.c_float), ("ms_shade", C.c_float),
                 ("ms_resolve", C.c_float), ("ms_total", C.c_float),
                 ("launches_trace", C.c_uint32), ("launches_shadow", C.c_uint32), ("launches_shade", C.c_uint32),
-                ("launches_total", C.c_uint32)]
+                ("launches_total", C.c_uint32), ("rays_sample_walked", C.c_uint64)]
 
     def total_rays(self):
         """Rays as SURVEY.md §8(d) counts them: every traversal query, incl. the root-AABB-only culled pixels."""

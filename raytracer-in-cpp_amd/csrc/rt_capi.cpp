@@ -759,7 +759,7 @@ static rt_status sum_frame_times(rt_ctx *c, size_t ev, int levels_run, rt_stats 
     for (int level = 0; level < levels_run; ++level) {
         if (lean) {
             // events: [.. trace ..] E [beam, shadow] E [shade] E [.. next trace ..]
-            ++ev;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_trace += ms; ++ev;
             HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_shadow += ms; ++ev;
             HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_shade += ms; ++ev;
         } else {
@@ -797,7 +797,7 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
     fold_stats(h);
     out->launches_total = c->frame_launches;
     if (std::getenv("RT_DEBUG")) std::fprintf(stderr, "RT_DEBUG level0: items %u tasks closest %u %u centre %u %u shadow %u %u\n", [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_items[0][sh * 16]; return t; }(), [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_task_tr[0][0][sh * 16]; return t; }(), 0u, [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_task_tr[0][1][sh * 16]; return t; }(), 0u, [&] { uint32_t t = 0; for (int sh = 0; sh < RT_LIST_SHARDS; ++sh) t += h.n_task_sh[0][sh * 16]; return t; }(), 0u);
-    out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample;
+    out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample; out->rays_sample_walked = h.sample_walked;
     out->pixels = F.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;
 #ifdef RT_UNIT_HIST
     if (!counted && c->S.dbg != nullptr) {
@@ -820,9 +820,9 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
         {
             static const char *nm[8] = {"walk-other", "pop+node-load(shaft: group load+shaft test)", "inner-children(shaft: survivors per-ray)", "leaf-tri-mode(shaft: leaves)", "leaf-scalar", "leaf-staged", "unit-setup(+queue)", "unit-finish"};
             for (int k = 0; k < 2; ++k) {
-                unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += h.prof[72 + 8 * k + i];
+                unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += h.prof[480 + 8 * k + i];
                 std::fprintf(stderr, "RT_PROFILE k_shadow%s wave-cycles by phase (total %llu):", k ? "<CONT>" : "", tot);
-                for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s=%.1f%%", nm[i], tot ? 100.0 * double(h.prof[72 + 8 * k + i]) / double(tot) : 0.0);
+                for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s=%.1f%%", nm[i], tot ? 100.0 * double(h.prof[480 + 8 * k + i]) / double(tot) : 0.0);
                 std::fprintf(stderr, "\n");
             }
         }
@@ -1043,7 +1043,7 @@ extern "C" rt_status rt_timing_collect(rt_ctx *c, rt_stats *out) {
     HIPCHK(c, hipMemcpy(&h, c->d_ctl, sizeof h, hipMemcpyDeviceToHost));
     { const rt_status os_ = check_overflow(c); if (os_ != RT_OK) return os_; }
     fold_stats(h);
-    out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample;
+    out->rays_primary = h.rays_primary; out->rays_bounce = h.rays_bounce; out->rays_centre = h.rays_centre; out->rays_sample = h.rays_sample; out->rays_sample_walked = h.sample_walked;
     out->pixels = c->pending_frame.npix; out->pixels_culled = h.pixels_culled; out->shaded_hits = h.shaded_hits;
     rt_status s = RT_OK;
     for (const auto &fr : c->pending)

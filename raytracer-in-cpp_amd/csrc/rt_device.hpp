@@ -178,7 +178,7 @@ struct DFrame {              // which pixels this launch covers
 #define RT_LIST_SHARDS 16
 #endif
 enum : int { ST_RAYS_PRIMARY = 0, ST_RAYS_BOUNCE, ST_RAYS_CENTRE, ST_RAYS_SAMPLE, ST_PIXELS_CULLED, ST_SHADED_HITS,
-             ST_BOX_TESTS, ST_LEAF_TRI_REFS, ST_BOX_TESTS_SHADOW, ST_LEAF_TRI_REFS_SHADOW };
+             ST_BOX_TESTS, ST_LEAF_TRI_REFS, ST_BOX_TESTS_SHADOW, ST_LEAF_TRI_REFS_SHADOW, ST_SAMPLE_WALKED };
 
 // control block in device memory (zeroed once per frame by a memset node on the render stream)
 struct Control {
@@ -200,6 +200,7 @@ struct Control {
     unsigned long long rays_primary, rays_bounce, rays_centre, rays_sample, pixels_culled, shaded_hits;
     unsigned long long box_tests, leaf_tri_refs;              // k_trace (closest hit + light-centre rays)
     unsigned long long box_tests_shadow, leaf_tri_refs_shadow; // k_shadow (area-light sample rays)
+    unsigned long long sample_walked;                          // sample shadow segments that were actually formed (not decided by k_beam / the per-unit culling tests)
     // what the kernels add to: one 128-byte line per shard, shard = blockIdx.x % RT_STAT_SHARDS.  (4096 waves adding
     // to ONE line at kernel end serialise in the memory-side atomic unit: measured 176 us for the 1080p primary k_trace
     // whose arithmetic needs < 20 us.)
@@ -221,6 +222,7 @@ inline void fold_stats(Control &h) {
     h.pixels_culled = t[ST_PIXELS_CULLED]; h.shaded_hits = t[ST_SHADED_HITS];
     h.box_tests = t[ST_BOX_TESTS]; h.leaf_tri_refs = t[ST_LEAF_TRI_REFS];
     h.box_tests_shadow = t[ST_BOX_TESTS_SHADOW]; h.leaf_tri_refs_shadow = t[ST_LEAF_TRI_REFS_SHADOW];
+    h.sample_walked = t[ST_SAMPLE_WALKED];
 }
 
 }  // namespace rtamd

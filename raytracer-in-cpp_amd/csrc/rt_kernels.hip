@@ -841,9 +841,11 @@ __device__ __forceinline__ void flat_walk(const DNode &root, const TriRec *__res
         return;
     }
     uint32_t k = 0;
+    RT_PROF_ADD(threadIdx.x & 63, 6, 1);
     for (; k + 1u < cnt; k += 2u) {          // two records per step: two independent chains in flight
         TriRec ta, tb;
         tri_load_uniform2(T + k, ta, tb);
+        RT_PROF_ADD(threadIdx.x & 63, 0, 2);
         test_one(ta);
         test_one(tb);
         if (ANY && !COUNT && (k & 6u) == 6u) {
@@ -851,7 +853,7 @@ __device__ __forceinline__ void flat_walk(const DNode &root, const TriRec *__res
             if (__ballot(mine) == 0ull) return;
         }
     }
-    if (k < cnt) test_one(tri_load_uniform(T + k));
+    if (k < cnt) { RT_PROF_ADD(threadIdx.x & 63, 0, 1); test_one(tri_load_uniform(T + k)); }
 }
 
 template <bool ANY, bool COUNT, bool FLAT, bool STAGED = true>
@@ -1822,6 +1824,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const DNode *__restrict
     if (F.dyn_trace) q.init(ctl->queue[ctr_slot], ntiles, gridDim.x * RT_WAVES, blockIdx.x, lane);
     else q.init_static(ntiles, gridDim.x * RT_WAVES, uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave)), lane);
     for (uint32_t tile = 0; q.next(tile);) {
+        RT_PROF_ADD(lane, 13, 1);
 #ifdef RT_PROFILE_HIST
         const long long prof_t0 = clock64();
         if (lane == 0) { stk.node[RT_STACK - 4] = 0; stk.node[RT_STACK - 3] = 0; stk.node[RT_STACK - 2] = 0; stk.node[RT_STACK - 1] = 0; }
@@ -2373,7 +2376,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(F
                                 fmaxf(pre_z0, pre_z1));
     }
 
-    uint32_t c_rays = 0, c_box = 0, c_ref = 0;
+    uint32_t c_rays = 0, c_box = 0, c_ref = 0, c_walked = 0;
     ShardedQueue q;
     uint32_t n_work = 0;
     ShardMap tmap{0u, 0u, 0u, 0u};
@@ -2544,6 +2547,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(F
             sroot = valid && (((seen >> s_in) & 1ull) != 0ull);
         } else {
             c_rays += valid ? 1u : 0u;
+            c_walked += valid ? 1u : 0u;                        // segments actually formed (units the culling devices left before this line formed none)
             if (COUNT && valid) c_box += 1;
             sroot = valid && box_hit_verified(root.bmin, sx, sy, sz, ddx, ddy, ddz, srx, sry, srz);
         }
@@ -2584,12 +2588,13 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(F
 #endif
     }
 #ifdef RT_PROFILE
-    pclk.flush(lane, CONT ? 80 : 72);
+    pclk.flush(lane, CONT ? 488 : 480);          // (prof[480, 496): clear of the step counters of both regions)
 #endif
-    c_rays = wave_sum(c_rays);
+    c_rays = wave_sum(c_rays); c_walked = wave_sum(c_walked);
     if (COUNT) { c_box = wave_sum(c_box); c_ref = wave_sum(c_ref); }
     if (lane == 0) {
         if (c_rays) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_SAMPLE], static_cast<unsigned long long>(c_rays));
+        if (c_walked) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_SAMPLE_WALKED], static_cast<unsigned long long>(c_walked));
         if (COUNT) {
             if (c_box) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_BOX_TESTS_SHADOW], static_cast<unsigned long long>(c_box));
             if (c_ref) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_LEAF_TRI_REFS_SHADOW], static_cast<unsigned long long>(c_ref));
@@ -2782,7 +2787,7 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
 #endif
     }
 #ifdef RT_PROFILE
-    pclk.flush(lane, 72);
+    pclk.flush(lane, 480);
     const uint32_t c_rays_dbg = wave_sum(c_rays);
     if (lane == 0 && g_prof) {
         const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
@@ -2809,7 +2814,10 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
     }
 #endif
     c_rays = wave_sum(c_rays);
-    if (lane == 0 && c_rays) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_SAMPLE], static_cast<unsigned long long>(c_rays));
+    if (lane == 0 && c_rays) {
+        atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_SAMPLE], static_cast<unsigned long long>(c_rays));
+        atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_SAMPLE_WALKED], static_cast<unsigned long long>(c_rays));     // the shaft walk forms every segment of its units
+    }
 }
 
 // ======================================================================================================
