@@ -1348,7 +1348,8 @@ __device__ __forceinline__ void shaft_walk(const DNode *__restrict__ nodes, cons
             // rejected here: skipping the per-ray content test on inner nodes (+8 % on cfg4), prefetching the next unit's item with a
             // scalar load (+4 %: 16 more live SGPRs -> spills) or through one VGPR with the queue looking one unit ahead (+6 %: the
             // other waves of the SIMD already cover that latency), the records of non-resident groups through an LDS slot instead of
-            // v_readlane (+1.5 % on cfg4), 2x / 4x / 8x larger k_stage grids (0 %).
+            // v_readlane (+1.5 % on cfg4), 2x / 4x / 8x larger k_stage grids (0 %), two survivors per step as independent chains (round 3:
+            // +3 % dodge, +7 % cfg4 -- the second record's registers are spilled).
             const DNode nd = resident ? sl.nodes[base + static_cast<uint32_t>(j)] : node_from_lane(ch, 8 * j);
             bool h = ((gm >> lane) & 1ull) != 0ull && !occluded;
             RT_PROF_ADD(lane, 74, __popcll(__ballot(h)));
@@ -2739,7 +2740,7 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         const float ddx = hx - sx, ddy = hy - sy, ddz = hz - sz;
         const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
         const unsigned long long vis_index = (static_cast<unsigned long long>(item_at) * static_cast<unsigned long long>(lslots) + static_cast<unsigned long long>(l)) * P + pass;
-        if (!CONT) c_rays += valid ? 1u : 0u;
+        if (!CONT) c_rays += static_cast<uint32_t>(__popcll(__ballot(valid)));      // wave-uniform: a scalar register, not a lane counter held (and spilled) across the walk
         ShaftLanes SL = make_shaft_lanes(lane, hx, hy, hz, fminf(x0, x1), fminf(y0, y1), fminf(z0, z1), fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1), S.extent);
         __builtin_amdgcn_wave_barrier();
         shaft_tri_store(sl.tri, lane, SL, hx, hy, hz, fminf(x0, x1), fminf(y0, y1), fminf(z0, z1), fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1));
@@ -2788,7 +2789,7 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
     }
 #ifdef RT_PROFILE
     pclk.flush(lane, 480);
-    const uint32_t c_rays_dbg = wave_sum(c_rays);
+    const uint32_t c_rays_dbg = c_rays;
     if (lane == 0 && g_prof) {
         const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
         atomicMax(&g_prof[101], t1);
@@ -2813,7 +2814,6 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
 #endif
     }
 #endif
-    c_rays = wave_sum(c_rays);
     if (lane == 0 && c_rays) {
         atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_SAMPLE], static_cast<unsigned long long>(c_rays));
         atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_SAMPLE_WALKED], static_cast<unsigned long long>(c_rays));     // the shaft walk forms every segment of its units
