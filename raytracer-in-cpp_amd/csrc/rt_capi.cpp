@@ -32,6 +32,7 @@ void launch_shadow_cont(int grid, hipStream_t st, const DScene &S, const DLights
 void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level, int slot, int lslots,
                   const ShadeItem *items, Control *ctl, const unsigned long long *vis, float4 *rec, float *fres, RayItem *rays_out);
 void launch_resolve(int grid, hipStream_t st, const DFrame &F, const float4 *rec, const float *fres, float *out_rgb, uint8_t *out_u8);
+void launch_deep(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level0, const RayItem *rays_in, Control *ctl, float4 *rec0, float *fres0);
 void launch_stage(bool primary, bool count, int stage, bool cont, int grid, hipStream_t st, const DScene &S, const DCam *camp, const DLights &L,
                   const DFrame &Fr, int level, int lslots, const RayItem *rays_in, ShadeItem *items, Control *ctl, float4 *rec, int32_t *out_hit,
                   float *out_t, unsigned long long *best, unsigned long long *lit, const TaskQueues &Q);
@@ -83,6 +84,7 @@ struct rt_ctx {
     uint32_t group_budget = 4u;                 // groups a trace unit pops before it hands the rest of its stack to the task launch (RT_GROUP_BUDGET, 0 = never)
     uint32_t shadow_budget = 3000u;
     bool beam_trees = false;
+    bool deep = true;                     // flat scenes: levels 2 .. max_depth in ONE launch (k_deep); RT_NO_DEEP=1 keeps the four launches per level
     int shaft_min_samples = 33;           // tree scenes: sample counts from which a (hit, light) pair gets a wave of its own (k_shadow_shaft)
     uint32_t shaft_budget = 0u;           // the shaft walk culls per triangle: its leaves are cheap enough to stay inline (dodge 1080p: 1.31 -> 1.22 ms without tasks)
     uint32_t shaft_budget_deep = 3000u;   // ... but the bounce levels have few units and a heavy tail: their big leaves do go to a leaf-task launch (cfg4 29.2 -> 28.3 ms)
@@ -152,6 +154,7 @@ extern "C" rt_status rt_create(rt_ctx **out, int device) {
     if (const char *sb = std::getenv("RT_SHAFT_BUDGET")) c->shaft_budget = c->shaft_budget_deep = static_cast<uint32_t>(std::atoi(sb));
     if (const char *sm = std::getenv("RT_SHAFT_MIN_SAMPLES")) c->shaft_min_samples = std::atoi(sm);
     if (const char *bt = std::getenv("RT_BEAM_TREES")) c->beam_trees = std::atoi(bt) != 0;
+    if (std::getenv("RT_NO_DEEP")) c->deep = false;
     if (const char *sg = std::getenv("RT_STAGED_TRACE")) c->staged_trace = std::atoi(sg) != 0;
     if (const char *sm = std::getenv("RT_STAGE_MULT")) { const int v = std::atoi(sm); if (v >= 1 && v <= 8) c->stage_mult = v; }
     if (const char *tc = std::getenv("RT_TASK_CAP")) { const long v = std::atol(tc); if (v >= 64 && v <= (1l << 24)) c->task_cap = static_cast<uint32_t>(v); }
@@ -690,7 +693,10 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
     // timed == 1: an event between every pair of launches (per-kernel breakdown; adds ~4 us per boundary)
     // timed == 2: lean set for timed loops -- frame start, around each k_shadow launch, frame end
     if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
-    for (int level = 0; level < levels_run; ++level) {
+    // flat scenes: the levels from 2 on are ONE launch (k_deep); the counting pass keeps the per-level kernels (its variants count per kernel)
+    const bool deep = c->flat && c->deep && !count && levels_run > 2;
+    const int wide_levels = deep ? 2 : levels_run;
+    for (int level = 0; level < wide_levels; ++level) {
         float4 *rec_l = c->d_rec + static_cast<size_t>(level) * F.npix;
         float *fres_l = c->d_fres + static_cast<size_t>(level) * F.npix;
         const bool prim = primary && level == 0;
@@ -743,6 +749,11 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
         launch_set_prof(st, c->d_ctl, 0u);
         ++nl, launch_shade(c->cus * c->occ_shade, st, c->S, L, F, level, 3 * level + 2, lslots, c->d_items, c->d_ctl, c->d_vis, rec_l, fres_l, c->d_rays[(level + 1) & 1]);
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));        // after k_shade (lean timing too: the shade interval is a single kernel)
+    }
+    if (deep) {
+        ++nl, launch_deep(c->cus * c->occ_shade, st, c->S, L, F, 2, c->d_rays[0], c->d_ctl, c->d_rec + 2 * static_cast<size_t>(F.npix), c->d_fres + 2 * static_cast<size_t>(F.npix));
+        // (the event layout stays three per level: the deep launch is booked as the trace interval of level 2, the other intervals are empty)
+        if (timed) for (int k = 0; k < 3 * (levels_run - 2); ++k) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
     }
     DFrame Fr = F;
     Fr.max_depth = levels_run - 1;

@@ -3299,6 +3299,105 @@ __device__ __forceinline__ float fresnel_term(float ix, float iy, float iz, floa
 #define RT_SHADE_WPE 4
 #endif
 #define RT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(RT_SHADE_WPE, 8)))
+// ---- phongShade / getInterpolatedNormal / the material dispatch of traceRay, shared by k_shade (visibility words from the shadow kernels) and
+// k_deep (the deep bounce levels of flat scenes, visibility computed in place).  Every function keeps the reference's operation order.
+struct ShadeHit {
+    float hx, hy, hz;            // hitPoint = origin + t * direction (flyscene.cpp:695)
+    float nx, ny, nz;            // (modelMatrix * interpolated normal).normalized()
+    float ex, ey, ez;            // eyeToHitPoint
+    float fnx, fny, fnz;         // face normal
+    rt_material mat;
+};
+__device__ __forceinline__ ShadeHit shade_hit(const DScene &S, const int face, const float ox, const float oy, const float oz, const float dx, const float dy,
+                                              const float dz, const float t) {
+    ShadeHit H;
+    const float hx = ox + t * dx, hy = oy + t * dy, hz = oz + t * dz;
+    const float *tv = S.tri_verts + static_cast<size_t>(face) * 9;
+    const float Ax = tv[0], Ay = tv[1], Az = tv[2], Bx = tv[3], By = tv[4], Bz = tv[5], Cx = tv[6], Cy = tv[7], Cz = tv[8];
+    const uint32_t ia = S.tri_vid[face * 3], ib = S.tri_vid[face * 3 + 1], ic = S.tri_vid[face * 3 + 2];
+    const float *nA = S.vert_normal + static_cast<size_t>(ia) * 3, *nB = S.vert_normal + static_cast<size_t>(ib) * 3,
+                *nC = S.vert_normal + static_cast<size_t>(ic) * 3;
+    H.mat = S.mats[S.mat_id[face]];
+    H.fnx = S.face_normal[face * 3]; H.fny = S.face_normal[face * 3 + 1]; H.fnz = S.face_normal[face * 3 + 2];
+    // getInterpolatedNormal (flyscene.cpp:864-888)
+    const float v0x = Bx - Ax, v0y = By - Ay, v0z = Bz - Az;
+    const float v1x = Cx - Ax, v1y = Cy - Ay, v1z = Cz - Az;
+    const float v2x = hx - Ax, v2y = hy - Ay, v2z = hz - Az;
+    const float d00 = dot3(v0x, v0y, v0z, v0x, v0y, v0z), d01 = dot3(v0x, v0y, v0z, v1x, v1y, v1z);
+    const float d11 = dot3(v1x, v1y, v1z, v1x, v1y, v1z);
+    const float d20 = dot3(v2x, v2y, v2z, v0x, v0y, v0z), d21 = dot3(v2x, v2y, v2z, v1x, v1y, v1z);
+    const float denom = d00 * d11 - d01 * d01;
+    const float bv = (d11 * d20 - d01 * d21) / denom;
+    const float bw = (d00 * d21 - d01 * d20) / denom;
+    const float bu = 1.0f - bv - bw;
+    const float inx = (bu * nA[0] + bv * nB[0]) + bw * nC[0];
+    const float iny = (bu * nA[1] + bv * nB[1]) + bw * nC[1];
+    const float inz = (bu * nA[2] + bv * nB[2]) + bw * nC[2];
+    // mesh.getModelMatrix() * n: Affine * Vector3f adds the translation (flyscene.cpp:829)
+    const float *M = S.model;
+    float nx = ((M[0] * inx + M[1] * iny) + M[2] * inz) + M[3] * 1.0f;
+    float ny = ((M[4] * inx + M[5] * iny) + M[6] * inz) + M[7] * 1.0f;
+    float nz = ((M[8] * inx + M[9] * iny) + M[10] * inz) + M[11] * 1.0f;
+    normalize3(nx, ny, nz);
+    // eyeToHitPoint = (-1 * (hitPoint - origin)).normalized(): invariant over samples
+    float ex = -1.0f * (hx - ox), ey = -1.0f * (hy - oy), ez = -1.0f * (hz - oz);
+    normalize3(ex, ey, ez);
+    H.hx = hx; H.hy = hy; H.hz = hz; H.nx = nx; H.ny = ny; H.nz = nz; H.ex = ex; H.ey = ey; H.ez = ez;
+    return H;
+}
+// the diffuse + specular term of ONE light sample at (sx, sy, sz) (flyscene.cpp:838-853), colour x material factors passed in
+__device__ __forceinline__ void phong_sample(const ShadeHit &H, const float sx, const float sy, const float sz, const float lkd0, const float lkd1, const float lkd2,
+                                             const float lks0, const float lks1, const float lks2, const double *__restrict__ tab, float &tr_, float &tg_, float &tb_) {
+    float ldx = sx - H.hx, ldy = sy - H.hy, ldz = sz - H.hz;
+    normalize3_shared(ldx, ldy, ldz);
+    const float ldn = dot3(ldx, ldy, ldz, H.nx, H.ny, H.nz);
+    const float costheta = smax(0.0f, ldn);
+    const float two = 2 * ldn;
+    float rx = ldx - two * H.nx, ry = ldy - two * H.ny, rz = ldz - two * H.nz;
+    normalize3_shared(rx, ry, rz);
+    const float cosphi = smax(0.0f, dot3(H.ex, H.ey, H.ez, -1.0f * rx, -1.0f * ry, -1.0f * rz));
+    const float pw = pow_shininess(cosphi, H.mat.shininess, tab);
+    tr_ = lkd0 * costheta + lks0 * pw; tg_ = lkd1 * costheta + lks1 * pw; tb_ = lkd2 * costheta + lks2 * pw;
+}
+// material dispatch of traceRay (flyscene.cpp:712-760); a hit at level == max_depth is plain Phong (extension).  Returns the blend kind; for
+// kinds other than KIND_CONST `child` is the spawned ray (origin, pix filled by the caller); illum 5 stores its Fresnel factor.
+__device__ __forceinline__ uint32_t material_dispatch(const ShadeHit &H, const bool may_spawn, const float dx, const float dy, const float dz, const float lx, const float ly,
+                                                      const float lz, const uint32_t lmode, RayItem &child, float *__restrict__ fres_pix) {
+    const int imodel = H.mat.illum;
+    uint32_t kind = KIND_CONST;
+    if (may_spawn) {
+        if (imodel == 9) {
+            kind = KIND_PASS;
+            child.dx = dx; child.dy = dy; child.dz = dz;
+            child.lx = lx; child.ly = ly; child.lz = lz; child.lmode = lmode;
+        } else if (imodel == 6) {
+            kind = KIND_REFRACT;
+            const float c1 = fabsf(dot3(dx, dy, dz, H.fnx, H.fny, H.fnz));
+            const float inv = 1 / H.mat.optical_density;
+            const double p1 = static_cast<double>(inv) * static_cast<double>(inv);     // pow((1/Ni), 2)
+            const double p2 = static_cast<double>(c1) * static_cast<double>(c1);       // pow(c1, 2)
+            const float c2 = static_cast<float>(sqrt(1 - p1 * (1 - p2)));
+            const float k = inv * c1 - c2;
+            child.dx = inv * dx + k * H.fnx; child.dy = inv * dy + k * H.fny; child.dz = inv * dz + k * H.fnz;
+            child.lx = lx; child.ly = ly; child.lz = lz; child.lmode = lmode;
+        } else if (imodel > 2 && imodel < 6) {
+            kind = imodel == 5 ? KIND_FRESNEL : KIND_MIRROR;
+            const float two = 2 * dot3(dx, dy, dz, H.fnx, H.fny, H.fnz);
+            child.dx = dx - two * H.fnx; child.dy = dy - two * H.fny; child.dz = dz - two * H.fnz;
+            child.lx = H.hx; child.ly = H.hy; child.lz = H.hz; child.lmode = 1u;             // reflectedLights = {hitPoint}
+            if (imodel == 5) *fres_pix = fresnel_term(child.dx, child.dy, child.dz, H.fnx, H.fny, H.fnz, H.mat.optical_density);
+        }
+    }
+    return kind;
+}
+__device__ __forceinline__ void pow_tables_to_lds(double *s_pow) {
+    if (threadIdx.x < RT_POW_TAB) {
+        const uint32_t ti = threadIdx.x;
+        s_pow[ti] = ti < 16u ? POWF_LOG2_INVC[ti] : (ti < 32u ? POWF_LOG2_LOGC[ti - 16u] : (ti < 64u ? __longlong_as_double(static_cast<long long>(POWF_EXP2_TAB[ti - 32u])) : POWF_CONST[ti - 64u]));
+    }
+    __syncthreads();
+}
+
 // SIMPLE: the light is a point or a grid of at most 64 samples (one visibility word per (hit, light), sample s = bit s, no 8 x 8 blocks, no
 // sphere offsets) -- the reference's own 5 x 5 and the 8 x 8 headline.  The sample loop then carries no word / block / mode branches.
 template <bool SIMPLE>
@@ -3307,11 +3406,7 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
                                                const unsigned long long *__restrict__ vis, float4 *__restrict__ rec,
                                                float *__restrict__ fres, RayItem *__restrict__ rays_out) {
     __shared__ double s_pow[RT_POW_TAB];       // powf tables: INVC[16] | LOGC[16] | EXP2_TAB[32] (bit patterns) | coefficients and thresholds [12]
-    if (threadIdx.x < RT_POW_TAB) {
-        const uint32_t ti = threadIdx.x;
-        s_pow[ti] = ti < 16u ? POWF_LOG2_INVC[ti] : (ti < 32u ? POWF_LOG2_LOGC[ti - 16u] : (ti < 64u ? __longlong_as_double(static_cast<long long>(POWF_EXP2_TAB[ti - 32u])) : POWF_CONST[ti - 64u]));
-    }
-    __syncthreads();
+    pow_tables_to_lds(s_pow);
     const int lane = threadIdx.x & 63;
     const ShardMap imap = shard_map(ctl->n_items[level], lane, F.item_cap, 1u, 64u);      // groups of 64 items, shard after shard
     const uint32_t ntiles = imap.total;
@@ -3331,40 +3426,7 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
         child.pad = 0u;
         if (valid) {
             c_shaded += 1;
-            const int face = it.face;
-            const float hx = it.ox + it.t * it.dx, hy = it.oy + it.t * it.dy, hz = it.oz + it.t * it.dz;
-            const float *tv = S.tri_verts + static_cast<size_t>(face) * 9;
-            const float Ax = tv[0], Ay = tv[1], Az = tv[2], Bx = tv[3], By = tv[4], Bz = tv[5], Cx = tv[6], Cy = tv[7], Cz = tv[8];
-            const uint32_t ia = S.tri_vid[face * 3], ib = S.tri_vid[face * 3 + 1], ic = S.tri_vid[face * 3 + 2];
-            const float *nA = S.vert_normal + static_cast<size_t>(ia) * 3, *nB = S.vert_normal + static_cast<size_t>(ib) * 3,
-                        *nC = S.vert_normal + static_cast<size_t>(ic) * 3;
-            const rt_material mat = S.mats[S.mat_id[face]];
-            const float fnx = S.face_normal[face * 3], fny = S.face_normal[face * 3 + 1], fnz = S.face_normal[face * 3 + 2];
-
-            // getInterpolatedNormal
-            const float v0x = Bx - Ax, v0y = By - Ay, v0z = Bz - Az;
-            const float v1x = Cx - Ax, v1y = Cy - Ay, v1z = Cz - Az;
-            const float v2x = hx - Ax, v2y = hy - Ay, v2z = hz - Az;
-            const float d00 = dot3(v0x, v0y, v0z, v0x, v0y, v0z), d01 = dot3(v0x, v0y, v0z, v1x, v1y, v1z);
-            const float d11 = dot3(v1x, v1y, v1z, v1x, v1y, v1z);
-            const float d20 = dot3(v2x, v2y, v2z, v0x, v0y, v0z), d21 = dot3(v2x, v2y, v2z, v1x, v1y, v1z);
-            const float denom = d00 * d11 - d01 * d01;
-            const float bv = (d11 * d20 - d01 * d21) / denom;
-            const float bw = (d00 * d21 - d01 * d20) / denom;
-            const float bu = 1.0f - bv - bw;
-            float inx = (bu * nA[0] + bv * nB[0]) + bw * nC[0];
-            float iny = (bu * nA[1] + bv * nB[1]) + bw * nC[1];
-            float inz = (bu * nA[2] + bv * nB[2]) + bw * nC[2];
-            // mesh.getModelMatrix() * n: Affine * Vector3f adds the translation (flyscene.cpp:829)
-            const float *M = S.model;
-            float nx = ((M[0] * inx + M[1] * iny) + M[2] * inz) + M[3] * 1.0f;
-            float ny = ((M[4] * inx + M[5] * iny) + M[6] * inz) + M[7] * 1.0f;
-            float nz = ((M[8] * inx + M[9] * iny) + M[10] * inz) + M[11] * 1.0f;
-            normalize3(nx, ny, nz);
-            // eyeToHitPoint = (-1 * (hitPoint - origin)).normalized(): invariant over samples
-            float ex = -1.0f * (hx - it.ox), ey = -1.0f * (hy - it.oy), ez = -1.0f * (hz - it.oz);
-            normalize3(ex, ey, ez);
-
+            const ShadeHit H = shade_hit(S, it.face, it.ox, it.oy, it.oz, it.dx, it.dy, it.dz, it.t);
             float fr = 0.f, fg = 0.f, fb = 0.f;
             const int nl = it.lmode ? 1 : L.n_lights;
             for (int l = 0; l < nl; ++l) {
@@ -3373,17 +3435,15 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
                 float sum = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
                 unsigned long long word = 0ull;
                 // The per-sample term is evaluated for EVERY sample and added as `visible ? term : +0` in sample order --
-                // identical to skipping invisible samples (x + 0 == x for the non-negative accumulators) but branch-free,
-                // so two samples' independent sqrt/divide chains can be in flight (ILP at 3 waves per SIMD).
-                const float lkd0 = L.color[0] * mat.kd[0], lkd1 = L.color[1] * mat.kd[1], lkd2 = L.color[2] * mat.kd[2];
-                const float lks0 = L.color[0] * mat.ks[0], lks1 = L.color[1] * mat.ks[1], lks2 = L.color[2] * mat.ks[2];
+                // identical to skipping invisible samples (x + 0 == x for the non-negative accumulators) but branch-free.
+                const float lkd0 = L.color[0] * H.mat.kd[0], lkd1 = L.color[1] * H.mat.kd[1], lkd2 = L.color[2] * H.mat.kd[2];
+                const float lks0 = L.color[0] * H.mat.ks[0], lks1 = L.color[1] * H.mat.ks[1], lks2 = L.color[2] * H.mat.ks[2];
                 const LightGrid lg = light_grid(L, px, py, pz);
                 uint32_t si = 0, sj = 0;                       // s = si * vsteps + sj, kept as counters: no division per sample
                 const uint32_t vst = static_cast<uint32_t>(L.vsteps > 0 ? L.vsteps : 1);
                 const bool blocks = !SIMPLE && sample_blocks(L);
                 const uint32_t bpr = vst >> 3;
                 if (SIMPLE) word = vw[0];
-#pragma unroll 2
                 for (uint32_t s = 0; s < N; ++s) {
                     uint32_t bit = s & 63u;
                     if (!SIMPLE) {
@@ -3400,16 +3460,8 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
                     grid_sample(lg, static_cast<float>(si) + 0.5f, static_cast<float>(sj) + 0.5f, sx, sy, sz);
                     if (!SIMPLE && L.mode == RT_LIGHT_SPHERE) sphere_sample(L, s, px, py, pz, sx, sy, sz);
                     if (++sj == vst) { sj = 0; ++si; }
-                    float ldx = sx - hx, ldy = sy - hy, ldz = sz - hz;
-                    normalize3_shared(ldx, ldy, ldz);
-                    const float ldn = dot3(ldx, ldy, ldz, nx, ny, nz);
-                    const float costheta = smax(0.0f, ldn);
-                    const float two = 2 * ldn;
-                    float rx = ldx - two * nx, ry = ldy - two * ny, rz = ldz - two * nz;
-                    normalize3_shared(rx, ry, rz);
-                    const float cosphi = smax(0.0f, dot3(ex, ey, ez, -1.0f * rx, -1.0f * ry, -1.0f * rz));
-                    const float pw = pow_shininess(cosphi, mat.shininess, s_pow);
-                    const float tr_ = lkd0 * costheta + lks0 * pw, tg_ = lkd1 * costheta + lks1 * pw, tb_ = lkd2 * costheta + lks2 * pw;
+                    float tr_, tg_, tb_;
+                    phong_sample(H, sx, sy, sz, lkd0, lkd1, lkd2, lks0, lks1, lks2, s_pow, tr_, tg_, tb_);
                     cr = cr + (visible ? tr_ : 0.0f);
                     cg = cg + (visible ? tg_ : 0.0f);
                     cb = cb + (visible ? tb_ : 0.0f);
@@ -3419,37 +3471,11 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
                 fg = fg + (cg * a) * b;
                 fb = fb + (cb * a) * b;
             }
-
-            // material dispatch (flyscene.cpp:712-760); a hit at level == max_depth is plain Phong (extension)
-            const int imodel = mat.illum;
-            uint32_t kind = KIND_CONST;
-            if (level < F.max_depth) {
-                if (imodel == 9) {
-                    kind = KIND_PASS;
-                    child.dx = it.dx; child.dy = it.dy; child.dz = it.dz;
-                    child.lx = it.lx; child.ly = it.ly; child.lz = it.lz; child.lmode = it.lmode;
-                } else if (imodel == 6) {
-                    kind = KIND_REFRACT;
-                    const float c1 = fabsf(dot3(it.dx, it.dy, it.dz, fnx, fny, fnz));
-                    const float inv = 1 / mat.optical_density;
-                    const double p1 = static_cast<double>(inv) * static_cast<double>(inv);     // pow((1/Ni), 2)
-                    const double p2 = static_cast<double>(c1) * static_cast<double>(c1);       // pow(c1, 2)
-                    const float c2 = static_cast<float>(sqrt(1 - p1 * (1 - p2)));
-                    const float k = inv * c1 - c2;
-                    child.dx = inv * it.dx + k * fnx; child.dy = inv * it.dy + k * fny; child.dz = inv * it.dz + k * fnz;
-                    child.lx = it.lx; child.ly = it.ly; child.lz = it.lz; child.lmode = it.lmode;
-                } else if (imodel > 2 && imodel < 6) {
-                    kind = imodel == 5 ? KIND_FRESNEL : KIND_MIRROR;
-                    const float two = 2 * dot3(it.dx, it.dy, it.dz, fnx, fny, fnz);
-                    child.dx = it.dx - two * fnx; child.dy = it.dy - two * fny; child.dz = it.dz - two * fnz;
-                    child.lx = hx; child.ly = hy; child.lz = hz; child.lmode = 1u;             // reflectedLights = {hitPoint}
-                    if (imodel == 5) fres[it.pix] = fresnel_term(child.dx, child.dy, child.dz, fnx, fny, fnz, mat.optical_density);
-                }
-            }
+            const uint32_t kind = material_dispatch(H, level < F.max_depth, it.dx, it.dy, it.dz, it.lx, it.ly, it.lz, it.lmode, child, &fres[it.pix]);
             rec[it.pix] = make_float4(fr, fg, fb, __uint_as_float(kind));
             if (kind != KIND_CONST) {
                 spawn = true;
-                child.ox = hx; child.oy = hy; child.oz = hz; child.pix = it.pix;
+                child.ox = H.hx; child.oy = H.hy; child.oz = H.hz; child.pix = it.pix;
             }
         }
         const unsigned long long sm = __ballot(spawn);
@@ -3462,6 +3488,144 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
     c_shaded = wave_sum(c_shaded);
     (void)c_spawn;
     if (lane == 0 && c_shaded) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_SHADED_HITS], static_cast<unsigned long long>(c_shaded));
+}
+
+// ======================================================================================================
+// K3b: the DEEP bounce levels of flat scenes (levels 2 .. max_depth), one launch.
+// A bounce level costs four launches (trace, beam, shadow, shade) whether anything reaches it or not: on a convex mirror object -- cube.obj, the
+// headline -- levels 2 .. 4 are empty and their 12 launches were 40 us of a 0.36 ms frame.  A pixel's chain of bounces depends on nothing but
+// itself, so here a wave takes 64 level-2 rays and carries them through ALL remaining levels on its own: closest hit and light-centre
+// visibility over the root leaf (flat_walk, as k_trace), then phongShade with the visibility of every light sample computed in place
+// (lane = hit, one flat_walk over the root leaf per sample: the segment lightStrikes would test), material dispatch, next level.  Nothing is
+// compacted and nothing is culled: every decision is the reference's own test on the ray itself, and the per-sample arithmetic is the code
+// k_shade runs (shade_hit / phong_sample / material_dispatch).  An empty level 2 is one launch that reads one counter.  Flat scenes only (a
+// root leaf of <= 64 triangles: a sample costs <= 64 triangle tests); tree scenes and levels 0 / 1 keep the wide kernels.
+// ======================================================================================================
+__global__ __launch_bounds__(256) RT_SHADE_ATTR void k_deep(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris, const DScene S, const DLights L, const DFrame F,
+                                                            const int level0, const RayItem *__restrict__ rays_in, Control *__restrict__ ctl,
+                                                            float4 *__restrict__ rec0, float *__restrict__ fres0) {
+    __shared__ double s_pow[RT_POW_TAB];
+    const int lane = threadIdx.x & 63;
+    const ShardMap rmap = shard_map(ctl->n_rays[level0], lane, 0xffffffffu, 1u, 64u);
+    const uint32_t ntiles = rmap.total;
+    if (ntiles == 0u) return;                     // nothing reaches the deep levels: every wave leaves here
+    pow_tables_to_lds(s_pow);
+    const DNode root = nodes[0];
+    const LanePlane pl0{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const uint32_t N = static_cast<uint32_t>(L.n_samples);
+    const uint32_t vst = static_cast<uint32_t>(L.vsteps > 0 ? L.vsteps : 1);
+    uint32_t c_rays = 0, c_centre = 0, c_sample = 0, c_shaded = 0, c_unused0 = 0, c_unused1 = 0;
+    const uint32_t wave_id = uniform_u32(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t wave_count = gridDim.x * 4u;
+    for (uint32_t tile = wave_id; tile < ntiles; tile += wave_count) {
+        uint32_t sh, tj, n_in;
+        shard_find(rmap, tile, sh, tj, n_in);
+        const uint32_t k = tj * 64u + static_cast<uint32_t>(lane);
+        bool alive = k < n_in;
+        const RayItem it0 = rays_in[alive ? sh * F.ray_cap + k : 0u];
+        float ox = it0.ox, oy = it0.oy, oz = it0.oz, dx = it0.dx, dy = it0.dy, dz = it0.dz, lx = it0.lx, ly = it0.ly, lz = it0.lz;
+        uint32_t lmode = it0.lmode;
+        const uint32_t pix = it0.pix;
+        for (int level = level0; level <= F.max_depth && __ballot(alive) != 0ull; ++level) {
+            float4 *__restrict__ rec = rec0 + static_cast<size_t>(level - level0) * F.npix;
+            float *__restrict__ fres = fres0 + static_cast<size_t>(level - level0) * F.npix;
+            // ---- traceRay: closest hit (flyscene.cpp:655-691), as k_trace
+            c_rays += alive ? 1u : 0u;
+            const float bx = (ox + dx) - ox, by = (oy + dy) - oy, bz = (oz + dz) - oz;
+            const float brx = __builtin_amdgcn_rcpf(bx), bry = __builtin_amdgcn_rcpf(by), brz = __builtin_amdgcn_rcpf(bz);
+            const bool in_root = alive && box_hit_verified(root.bmin, ox, oy, oz, bx, by, bz, brx, bry, brz);
+            float best_t = 3.402823466e+38f;
+            int best_f = -1;
+            bool dummy = false;
+            flat_walk<false, false>(root, tris, in_root, seg_off(), 0ull, pl0, ox, oy, oz, dx, dy, dz, best_t, best_f, dummy, c_unused0, c_unused1);
+            const bool hit = alive && (best_f >= 0) && (static_cast<uint32_t>(best_f) < S.n_faces);
+            const float hx = ox + best_t * dx, hy = oy + best_t * dy, hz = oz + best_t * dz;   // flyscene.cpp:695
+            // ---- lightStrikes(hitPoint, lights): one segment per light centre (flyscene.cpp:700)
+            bool lit = false;
+            const int nl_lane = lmode ? 1 : L.n_lights;
+            const int nl_wave = (__ballot(hit && lmode == 0u) != 0ull) ? L.n_lights : 1;
+            if (__ballot(hit) != 0ull) {
+                for (int l = 0; l < nl_wave; ++l) {
+                    const bool act = hit && (l < nl_lane);
+                    const float px = lmode ? lx : L.pos[l][0], py = lmode ? ly : L.pos[l][1], pz = lmode ? lz : L.pos[l][2];
+                    const float sdx = hx - px, sdy = hy - py, sdz = hz - pz;
+                    c_centre += act ? 1u : 0u;
+                    const float srx = __builtin_amdgcn_rcpf(sdx), sry = __builtin_amdgcn_rcpf(sdy), srz = __builtin_amdgcn_rcpf(sdz);
+                    const bool sroot = act && box_hit_verified(root.bmin, px, py, pz, sdx, sdy, sdz, srx, sry, srz);
+                    float t_unused = 0.f; int f_unused = -1;
+                    bool occ = false;
+                    flat_walk<true, false>(root, tris, sroot, seg_off(), 0ull, pl0, px, py, pz, sdx, sdy, sdz, t_unused, f_unused, occ, c_unused0, c_unused1);
+                    lit = lit || (act && !occ);
+                }
+            }
+            if (alive) {
+                if (!hit) rec[pix] = make_float4(1.f, 1.f, 1.f, __uint_as_float(KIND_CONST));          // BACKGROUND
+                else if (!lit) rec[pix] = make_float4(0.f, 0.f, 0.f, __uint_as_float(KIND_CONST));     // SHADOW
+            }
+            alive = lit;
+            if (__ballot(lit) == 0ull) break;
+            // ---- phongShade (flyscene.cpp:822-859): the lanes that hold a lit hit; every sample's lightStrikes segment is walked in place
+            c_shaded += lit ? 1u : 0u;
+            const int face = lit ? best_f : 0;
+            const ShadeHit H = shade_hit(S, face, ox, oy, oz, dx, dy, dz, lit ? best_t : 0.0f);      // (lanes without a lit hit: finite stand-in values, never stored)
+            float fr = 0.f, fg = 0.f, fb = 0.f;
+            const int nl_shade = (__ballot(lit && lmode == 0u) != 0ull) ? L.n_lights : 1;
+            const float lkd0 = L.color[0] * H.mat.kd[0], lkd1 = L.color[1] * H.mat.kd[1], lkd2 = L.color[2] * H.mat.kd[2];
+            const float lks0 = L.color[0] * H.mat.ks[0], lks1 = L.color[1] * H.mat.ks[1], lks2 = L.color[2] * H.mat.ks[2];
+            for (int l = 0; l < nl_shade; ++l) {
+                const bool act = lit && (l < nl_lane);
+                const float px = lmode ? lx : L.pos[l][0], py = lmode ? ly : L.pos[l][1], pz = lmode ? lz : L.pos[l][2];
+                const LightGrid lg = light_grid(L, px, py, pz);
+                float sum = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+                uint32_t si = 0, sj = 0;
+                for (uint32_t s = 0; s < N; ++s) {
+                    float sx, sy, sz;
+                    grid_sample(lg, static_cast<float>(si) + 0.5f, static_cast<float>(sj) + 0.5f, sx, sy, sz);
+                    if (L.mode == RT_LIGHT_SPHERE) sphere_sample(L, s, px, py, pz, sx, sy, sz);
+                    if (++sj == vst) { sj = 0; ++si; }
+                    // lightStrikes(hitPoint, {sample}): origin = sample, direction = hitPoint - sample (flyscene.cpp:912-954), as k_shadow forms it
+                    const float ddx = H.hx - sx, ddy = H.hy - sy, ddz = H.hz - sz;
+                    const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
+                    c_sample += act ? 1u : 0u;
+                    const bool sroot = act && box_hit_verified(root.bmin, sx, sy, sz, ddx, ddy, ddz, srx, sry, srz);
+                    float t_unused = 0.f; int f_unused = -1;
+                    bool occ = false;
+                    flat_walk<true, false>(root, tris, sroot, seg_off(), 0ull, pl0, sx, sy, sz, ddx, ddy, ddz, t_unused, f_unused, occ, c_unused0, c_unused1);
+                    const bool visible = act && !occ;
+                    sum += visible ? 1.0f : 0.0f;
+                    float tr_, tg_, tb_;
+                    phong_sample(H, sx, sy, sz, lkd0, lkd1, lkd2, lks0, lks1, lks2, s_pow, tr_, tg_, tb_);
+                    cr = cr + (visible ? tr_ : 0.0f);
+                    cg = cg + (visible ? tg_ : 0.0f);
+                    cb = cb + (visible ? tb_ : 0.0f);
+                }
+                const float a = sum / static_cast<float>(N), b = 1.3f / static_cast<float>(N);
+                fr = act ? fr + (cr * a) * b : fr;
+                fg = act ? fg + (cg * a) * b : fg;
+                fb = act ? fb + (cb * a) * b : fb;
+            }
+            RayItem child;
+            child.pad = 0u;
+            uint32_t kind = KIND_CONST;
+            if (lit) {
+                kind = material_dispatch(H, level < F.max_depth, dx, dy, dz, lx, ly, lz, lmode, child, &fres[pix]);
+                rec[pix] = make_float4(fr, fg, fb, __uint_as_float(kind));
+            }
+            alive = lit && kind != KIND_CONST;
+            if (alive) {       // the child ray of this lane: origin = hitPoint
+                ox = H.hx; oy = H.hy; oz = H.hz; dx = child.dx; dy = child.dy; dz = child.dz;
+                lx = child.lx; ly = child.ly; lz = child.lz; lmode = child.lmode;
+            }
+        }
+    }
+    c_rays = wave_sum(c_rays); c_centre = wave_sum(c_centre); c_sample = wave_sum(c_sample); c_shaded = wave_sum(c_shaded);
+    if (lane == 0) {
+        unsigned long long *st = ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)];
+        if (c_rays) atomicAdd(&st[ST_RAYS_BOUNCE], static_cast<unsigned long long>(c_rays));
+        if (c_centre) atomicAdd(&st[ST_RAYS_CENTRE], static_cast<unsigned long long>(c_centre));
+        if (c_sample) { atomicAdd(&st[ST_RAYS_SAMPLE], static_cast<unsigned long long>(c_sample)); atomicAdd(&st[ST_SAMPLE_WALKED], static_cast<unsigned long long>(c_sample)); }
+        if (c_shaded) atomicAdd(&st[ST_SHADED_HITS], static_cast<unsigned long long>(c_shaded));
+    }
 }
 
 // ======================================================================================================
@@ -3717,6 +3881,10 @@ void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, c
         hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(256), 0, st, S, L, F, level, slot, lslots, items, ctl, vis, rec, fres, rays_out);
     else
         hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(256), 0, st, S, L, F, level, slot, lslots, items, ctl, vis, rec, fres, rays_out);
+}
+
+void launch_deep(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level0, const RayItem *rays_in, Control *ctl, float4 *rec0, float *fres0) {
+    hipLaunchKernelGGL(k_deep, dim3(grid), dim3(256), 0, st, S.nodes, S.leaf_tris, S, L, F, level0, rays_in, ctl, rec0, fres0);
 }
 
 void launch_resolve(int grid, hipStream_t st, const DFrame &F, const float4 *rec, const float *fres, float *out_rgb, uint8_t *out_u8) {

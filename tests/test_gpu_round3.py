@@ -182,3 +182,46 @@ def test_sphere_graph_survives_later_sphere_calls(rt, scene):
     g.launch(cam); g.stats()
     assert np.array_equal(out.to_numpy(np.float32, (h, w, 3)).view(np.uint32), want.view(np.uint32))
     g.close(); out.free(); ctx.close(); hs.close()
+
+
+# ------------------------------------------------------------------------------------------ k_deep: levels 2.. of flat scenes in one launch
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,u,depth,lights", [("mixed", 5, 4, 1), ("mixed", 8, 8, 1), ("mixed", 4, 6, 3), ("cube", 8, 4, 1), ("mixed", 12, 5, 2)])
+def test_deep_levels_in_one_launch_equal_the_wide_kernels_and_the_oracle(rt, oracle, tmp_path, monkeypatch, which, u, depth, lights):
+    """Flat scenes run their bounce levels >= 2 in ONE launch (k_deep: a wave carries 64 rays through all remaining levels, every sample's
+    lightStrikes segment walked in place).  The frame, the hit ids and the ray counters equal the four-launches-per-level path (RT_NO_DEEP=1)
+    and the oracle bit for bit -- on the mixed-material scene (illum 2/3/5/6/7/9: populated deep levels, own light lists after a mirror
+    bounce, pass-through and refraction chains), with one word, several words (12 x 12) and several lights."""
+    import scenes_gen
+    path = scenes_gen.mixed_materials(str(tmp_path)) if which == "mixed" else os.path.join(SCENES, "cube.obj")
+    pts = [(-1.0, 1.0, 1.0), (0.8, 0.4, 1.5), (0.0, 0.0, 2.0)][:lights]
+    w, h = 224, 152
+    cam, L = rt.default_camera(w, h, 0.4 if which == "mixed" else 0.0), rt.make_lights(points=pts, area=True, usteps=u, vsteps=u)
+    hs = rt.HostScene(path, 1000, 15)
+    frames, stats = [], []
+    for no_deep in (False, True):
+        if no_deep:
+            monkeypatch.setenv("RT_NO_DEEP", "1")
+        ctx = rt.Context(0)
+        ctx.upload(hs)
+        p = rt.make_params(w, h, depth)
+        rgb = np.zeros((h, w, 3), np.float32)
+        hits = np.zeros((h, w), np.int32)
+        st = rt.capi.rt_stats()
+        rc = ctx.lib.rt_render(ctx.handle, C.byref(cam), C.byref(L), C.byref(p), rgb.ctypes.data_as(C.c_void_p), hits.ctypes.data_as(C.c_void_p), C.byref(st))
+        rt.capi.check(ctx.lib, ctx.handle, rc, "rt_render")
+        frames.append((rgb, hits))
+        stats.append((st.rays_primary, st.rays_bounce, st.rays_centre, st.rays_sample, st.shaded_hits, st.launches_total))
+        ctx.close()
+    assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32)) and np.array_equal(frames[0][1], frames[1][1])
+    assert stats[0][:5] == stats[1][:5]
+    if depth >= 3:
+        assert stats[0][5] < stats[1][5]                       # fewer launches per frame
+    osc = oracle.load_scene(path)
+    ref, rhits, ost = osc.render(oracle.camera(w, h, 0.4 if which == "mixed" else 0.0), oracle.lights(area=True, usteps=u, vsteps=u, points=pts), w, h,
+                                 max_depth=depth, threads=8, want_hits=True)
+    assert_exact(frames[0][0], frames[0][1], ref, rhits)
+    assert (stats[0][1], stats[0][2], stats[0][3]) == (ost.rays_bounce, ost.rays_centre, ost.rays_sample)
+    if which == "mixed":
+        assert ost.rays_bounce > 0
+    osc.close(); hs.close()
