@@ -30,7 +30,7 @@ void launch_shadow_cont(int grid, hipStream_t st, const DScene &S, const DLights
                         Control *ctl, unsigned long long *vis, const ContTask *tasks_in, ContTask *tasks_out, uint32_t q_in, uint32_t q_out,
                         uint32_t cap, uint32_t budget, const uint32_t *sidx);
 void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level, int slot, int lslots,
-                  const ShadeItem *items, Control *ctl, const unsigned long long *vis, float4 *rec, float *fres, RayItem *rays_out);
+                  const ShadeItem *items, Control *ctl, const unsigned long long *vis, float4 *rec, float *fres, RayItem *rays_out, bool resolve_flat);
 void launch_resolve(int grid, hipStream_t st, const DFrame &F, const float4 *rec, const float *fres, float *out_rgb, uint8_t *out_u8);
 void launch_deep(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level0, const RayItem *rays_in, Control *ctl, float4 *rec0, float *fres0);
 void launch_stage(bool primary, bool count, int stage, bool cont, int grid, hipStream_t st, const DScene &S, const DCam *camp, const DLights &L,
@@ -540,8 +540,11 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     query_occupancy(c->flat, &c->occ_trace_primary, &c->occ_trace_rays, &c->occ_shadow, &c->occ_shaft, &c->occ_shade);
     // k_trace uses static tile striding: with more than ~4 blocks/CU a wave owns so few tiles (32,400 tiles at 1080p)
     // that heavy object tiles no longer average out (measured 0.26 ms at 4 blocks/CU vs 0.38 ms at 7-8)
-    if (c->occ_trace_primary > 4) c->occ_trace_primary = 4;
-    if (c->occ_trace_rays > 4) c->occ_trace_rays = 4;
+    int trace_cap = 6;         // (round 3, RT_TRACE_OCC sweep on the cube frame: 3 / 4 / 5 / 6 / 8 blocks per CU -> trace group 76 / 80 / 76 / 68 / 78 us; round 1's cap of 4
+                               // dated from the single-counter compaction lists)
+    if (const char *tc = std::getenv("RT_TRACE_OCC")) { const int v = std::atoi(tc); if (v >= 1 && v <= 8) trace_cap = v; }
+    if (c->occ_trace_primary > trace_cap) c->occ_trace_primary = trace_cap;
+    if (c->occ_trace_rays > trace_cap) c->occ_trace_rays = trace_cap;
     c->occ_trace_primary *= c->grid_mult; c->occ_trace_rays *= c->grid_mult; c->occ_shadow *= c->grid_mult; c->occ_shaft *= c->grid_mult; c->occ_shade *= c->grid_mult;
     c->has_scene = true;
     return RT_OK;
@@ -747,7 +750,8 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
                                c->task_cap, 0u, sidx);
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));   // after the whole shadow group (incl. continuations)
         launch_set_prof(st, c->d_ctl, 0u);
-        ++nl, launch_shade(c->cus * c->occ_shade, st, c->S, L, F, level, 3 * level + 2, lslots, c->d_items, c->d_ctl, c->d_vis, rec_l, fres_l, c->d_rays[(level + 1) & 1]);
+        ++nl, launch_shade(c->cus * c->occ_shade, st, c->S, L, F, level, 3 * level + 2, lslots, c->d_items, c->d_ctl, c->d_vis, rec_l, fres_l, c->d_rays[(level + 1) & 1],
+                           c->flat && c->deep && !count && level + 1 < levels_run);
         if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));        // after k_shade (lean timing too: the shade interval is a single kernel)
     }
     if (deep) {

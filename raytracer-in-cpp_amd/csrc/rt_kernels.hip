@@ -1782,6 +1782,25 @@ __device__ __forceinline__ void light_sample(const DLights &L, const float px, c
 
 // Camera::screenToWorld (camera.hpp:155-173): raster -> [-1,1] in double, cast, perspective scale, inverse view.  One definition for
 // the fused k_trace, the staged k_stage and the probe kernel (rt_primary_points).
+// the same point for the pixel (x0 + (lane & 7), y0 + (lane >> 3)) of an 8 x 8 tile, with the tile's sixteen double divisions done ONCE: lane c < 8
+// evaluates the column term of x0 + c, lane 8 + r the row term of row ys[r] (the caller passes each lane ITS candidate: the row of lane 8 + r is
+// the y of the lanes r * 8 .. r * 8 + 7), every lane then fetches its two terms.  Same double operations on the same operands as screen_point --
+// 2 divisions per lane become 1 (a double division is ~30 half-rate instructions: a third of what a sky tile costs).
+__device__ __forceinline__ void screen_point_tile(const DCam &cam, const int lane, const int x0, const int y_of_row_lane, float &sx, float &sy, float &sz) {
+    const bool col = lane < 8;
+    const float f = col ? static_cast<float>(x0 + lane) : static_cast<float>(y_of_row_lane);
+    const double q = 2.0 * static_cast<double>(f - (col ? cam.vp[0] : cam.vp[1])) / static_cast<double>(col ? cam.vp[2] : cam.vp[3]);
+    const float term = col ? static_cast<float>(q - 1.0) : static_cast<float>(1.0 - q);
+    float n0 = __shfl(term, lane & 7, 64);
+    float n1 = __shfl(term, 8 + (lane >> 3), 64);
+    const float n2 = -1.0f;
+    n0 = n0 * cam.k0;
+    n1 = n1 * cam.k1;
+    const float *m = cam.inv_view;
+    sx = ((m[0] * n0 + m[1] * n1) + m[2] * n2) + m[3] * 1.0f;
+    sy = ((m[4] * n0 + m[5] * n1) + m[6] * n2) + m[7] * 1.0f;
+    sz = ((m[8] * n0 + m[9] * n1) + m[10] * n2) + m[11] * 1.0f;
+}
 __device__ __forceinline__ void screen_point(const DCam &cam, const int x, const int y, float &sx, float &sy, float &sz) {
     const float fi = static_cast<float>(x), fj = static_cast<float>(y);
     float n0 = static_cast<float>(2.0 * static_cast<double>(fi - cam.vp[0]) / static_cast<double>(cam.vp[2]) - 1.0);
@@ -1838,10 +1857,13 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_trace(const DNode *__restrict
             const int tx = static_cast<int>(tile % static_cast<uint32_t>(F.tiles_x)), ty = static_cast<int>(tile / static_cast<uint32_t>(F.tiles_x));
             const int x = tx * 8 + (lane & 7), lr = ty * 8 + (lane >> 3);
             valid = (x < F.width) && (lr < F.local_rows);
-            const int y = F.row0 + ((lr / F.stripe) * F.nranks + F.rank) * F.stripe + (lr % F.stripe);
             pix = static_cast<uint32_t>(lr) * static_cast<uint32_t>(F.width) + static_cast<uint32_t>(x);
             float sx, sy, sz;
-            screen_point(cam, x, y, sx, sy, sz);
+            {   // (lane 8 + r evaluates the row term of tile row r: the frame row of local row ty * 8 + r)
+                const int lr_r = ty * 8 + ((lane - 8) & 7);
+                const int y_r = F.row0 + ((lr_r / F.stripe) * F.nranks + F.rank) * F.stripe + (lr_r % F.stripe);
+                screen_point_tile(cam, lane, tx * 8, y_r, sx, sy, sz);
+            }
             ox = cam.center[0]; oy = cam.center[1]; oz = cam.center[2];
             dx = sx - ox; dy = sy - oy; dz = sz - oz;          // direction = screen - origin (UNNORMALISED), flyscene.cpp:619
             const bool pre = valid && box_hit_verified(root.bmin, ox, oy, oz, dx, dy, dz, __builtin_amdgcn_rcpf(dx), __builtin_amdgcn_rcpf(dy), __builtin_amdgcn_rcpf(dz));   // flyscene.cpp:576
@@ -1965,10 +1987,13 @@ __device__ __forceinline__ TileRay tile_ray(const uint32_t tile, const int lane,
         const int tx = static_cast<int>(tile % static_cast<uint32_t>(F.tiles_x)), ty = static_cast<int>(tile / static_cast<uint32_t>(F.tiles_x));
         const int x = tx * 8 + (lane & 7), lr = ty * 8 + (lane >> 3);
         r.valid = (x < F.width) && (lr < F.local_rows);
-        const int y = F.row0 + ((lr / F.stripe) * F.nranks + F.rank) * F.stripe + (lr % F.stripe);
         r.pix = static_cast<uint32_t>(lr) * static_cast<uint32_t>(F.width) + static_cast<uint32_t>(x);
         float sx, sy, sz;
-        screen_point(cam, x, y, sx, sy, sz);
+        {   // (lane 8 + r evaluates the row term of tile row r: the frame row of local row ty * 8 + r)
+            const int lr_r = ty * 8 + ((lane - 8) & 7);
+            const int y_r = F.row0 + ((lr_r / F.stripe) * F.nranks + F.rank) * F.stripe + (lr_r % F.stripe);
+            screen_point_tile(cam, lane, tx * 8, y_r, sx, sy, sz);
+        }
         r.ox = cam.center[0]; r.oy = cam.center[1]; r.oz = cam.center[2];
         r.dx = sx - r.ox; r.dy = sy - r.oy; r.dz = sz - r.oz;          // flyscene.cpp:619
         r.pre = r.valid && box_hit_verified(root.bmin, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, __builtin_amdgcn_rcpf(r.dx),
@@ -3356,7 +3381,10 @@ __device__ __forceinline__ void phong_sample(const ShadeHit &H, const float sx, 
     float rx = ldx - two * H.nx, ry = ldy - two * H.ny, rz = ldz - two * H.nz;
     normalize3_shared(rx, ry, rz);
     const float cosphi = smax(0.0f, dot3(H.ex, H.ey, H.ez, -1.0f * rx, -1.0f * ry, -1.0f * rz));
-    const float pw = pow_shininess(cosphi, H.mat.shininess, tab);
+    // (the eye on the far side of the reflected ray for EVERY hit of the wave: powf(+0, Ns) = +0 for a positive finite Ns -- e_powf.c's zero case --
+    //  without the 60-instruction double-precision path; one wave-uniform test)
+    const bool zero_pow = cosphi == 0.0f && H.mat.shininess > 0.0f && H.mat.shininess < __uint_as_float(0x7f800000u);
+    const float pw = (__ballot(!zero_pow) == 0ull) ? 0.0f : pow_shininess(cosphi, H.mat.shininess, tab);
     tr_ = lkd0 * costheta + lks0 * pw; tg_ = lkd1 * costheta + lks1 * pw; tb_ = lkd2 * costheta + lks2 * pw;
 }
 // material dispatch of traceRay (flyscene.cpp:712-760); a hit at level == max_depth is plain Phong (extension).  Returns the blend kind; for
@@ -3400,8 +3428,13 @@ __device__ __forceinline__ void pow_tables_to_lds(double *s_pow) {
 
 // SIMPLE: the light is a point or a grid of at most 64 samples (one visibility word per (hit, light), sample s = bit s, no 8 x 8 blocks, no
 // sphere offsets) -- the reference's own 5 x 5 and the 8 x 8 headline.  The sample loop then carries no word / block / mode branches.
-template <bool SIMPLE>
-__global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, const DLights L, const DFrame F, const int level, const int ctr_slot,
+// FLAT: the scene is one root leaf.  A spawned child ray is then tested against that leaf right here (the closest-hit walk k_trace would run for
+// it at the next level: ~45 instructions per triangle for the whole tile); a child that hits nothing gets its BACKGROUND record now and never
+// becomes a ray -- on a convex mirror object (cube.obj) that is every child: level 1 stays empty, its 576k-ray k_trace launch (24 us) is gone.
+// Children that do hit something go through the wide kernels as before (their walk is repeated there: the exception, not the rule).
+template <bool SIMPLE, bool FLAT>
+__global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris, const DScene S, const DLights L, const DFrame F,
+                                               const int level, const int ctr_slot,
                                                const int lslots, const ShadeItem *__restrict__ items, Control *__restrict__ ctl,
                                                const unsigned long long *__restrict__ vis, float4 *__restrict__ rec,
                                                float *__restrict__ fres, RayItem *__restrict__ rays_out) {
@@ -3412,9 +3445,11 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
     const uint32_t ntiles = imap.total;
     const uint32_t N = static_cast<uint32_t>(L.n_samples);
     const uint32_t P = (N + 63u) / 64u;
-    uint32_t c_shaded = 0, c_spawn = 0;
+    uint32_t c_shaded = 0, c_spawn = 0, c_resolved = 0;
     const uint32_t wave_id = uniform_u32(blockIdx.x * 4u + (threadIdx.x >> 6));
     const uint32_t wave_count = gridDim.x * 4u;
+    DNode root;
+    if (FLAT) root = nodes[0];
     for (uint32_t tile = wave_id; tile < ntiles; tile += wave_count) {
         uint32_t sh, tj, n_sh;
         shard_find(imap, tile, sh, tj, n_sh);
@@ -3478,6 +3513,24 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
                 child.ox = H.hx; child.oy = H.hy; child.oz = H.hz; child.pix = it.pix;
             }
         }
+        if (FLAT && __ballot(spawn) != 0ull) {
+            // traceRay of the child, closest hit only (flyscene.cpp:655-691), exactly as k_trace runs it; no hit -> BACKGROUND at the next level
+            const float bx = (child.ox + child.dx) - child.ox, by = (child.oy + child.dy) - child.oy, bz = (child.oz + child.dz) - child.oz;
+            const float brx = __builtin_amdgcn_rcpf(bx), bry = __builtin_amdgcn_rcpf(by), brz = __builtin_amdgcn_rcpf(bz);
+            const bool in_root = spawn && box_hit_verified(root.bmin, child.ox, child.oy, child.oz, bx, by, bz, brx, bry, brz);
+            float best_t = 3.402823466e+38f;
+            int best_f = -1;
+            bool dummy = false;
+            uint32_t cu0 = 0, cu1 = 0;
+            flat_walk<false, false>(root, tris, in_root, seg_off(), 0ull, LanePlane{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, child.ox, child.oy, child.oz, child.dx, child.dy, child.dz,
+                                    best_t, best_f, dummy, cu0, cu1);
+            const bool hit = (best_f >= 0) && (static_cast<uint32_t>(best_f) < S.n_faces);
+            if (spawn && !hit) {
+                rec[static_cast<size_t>(F.npix) + child.pix] = make_float4(1.f, 1.f, 1.f, __uint_as_float(KIND_CONST));          // BACKGROUND (level + 1)
+                c_resolved += 1;                      // a bounce ray that was traced here
+                spawn = false;
+            }
+        }
         const unsigned long long sm = __ballot(spawn);
         if (sm != 0ull) {
             bool fits;
@@ -3488,6 +3541,10 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DScene S, con
     c_shaded = wave_sum(c_shaded);
     (void)c_spawn;
     if (lane == 0 && c_shaded) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_SHADED_HITS], static_cast<unsigned long long>(c_shaded));
+    if (FLAT) {
+        c_resolved = wave_sum(c_resolved);
+        if (lane == 0 && c_resolved) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_BOUNCE], static_cast<unsigned long long>(c_resolved));
+    }
 }
 
 // ======================================================================================================
@@ -3787,7 +3844,7 @@ void query_occupancy(bool flat, int *trace_primary, int *trace_rays, int *shadow
         *shadow = q(k_shadow<false, false, false>, RT_WAVES * 64, 4);
         *shaft_out = q((k_shadow_shaft<false, false>), RT_WAVES * 64, 4);      // (its grid used to be the smaller of the two residencies: 4 of its 6 waves per SIMD)
     }
-    *shade = q(k_shade<true>, 256, 2);
+    *shade = flat ? q((k_shade<true, true>), 256, 2) : q((k_shade<true, false>), 256, 2);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -3876,11 +3933,12 @@ void launch_beam(int grid, hipStream_t st, const DScene &S, const DLights &L, in
 }
 
 void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level, int slot, int lslots,
-                  const ShadeItem *items, Control *ctl, const unsigned long long *vis, float4 *rec, float *fres, RayItem *rays_out) {
-    if (L.mode != RT_LIGHT_SPHERE && L.n_samples <= 64)
-        hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(256), 0, st, S, L, F, level, slot, lslots, items, ctl, vis, rec, fres, rays_out);
-    else
-        hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(256), 0, st, S, L, F, level, slot, lslots, items, ctl, vis, rec, fres, rays_out);
+                  const ShadeItem *items, Control *ctl, const unsigned long long *vis, float4 *rec, float *fres, RayItem *rays_out, bool resolve_flat) {
+    const bool simple = L.mode != RT_LIGHT_SPHERE && L.n_samples <= 64;
+    const dim3 g(grid), b(256);
+#define RT_LAUNCH_SHADE(SI, FL) hipLaunchKernelGGL((k_shade<SI, FL>), g, b, 0, st, S.nodes, S.leaf_tris, S, L, F, level, slot, lslots, items, ctl, vis, rec, fres, rays_out)
+    if (simple) { if (resolve_flat) RT_LAUNCH_SHADE(true, true); else RT_LAUNCH_SHADE(true, false); }
+    else { if (resolve_flat) RT_LAUNCH_SHADE(false, true); else RT_LAUNCH_SHADE(false, false); }
 }
 
 void launch_deep(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level0, const RayItem *rays_in, Control *ctl, float4 *rec0, float *fres0) {
