@@ -3221,12 +3221,7 @@ __device__ const unsigned long long POWF_EXP2_TAB[32] = {
     0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
     0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
 
-// The polynomial coefficients and thresholds of e_powf.c, kept behind the tables in LDS ([64, 76)): as literals every one of them is
-// re-materialised with two v_mov per use inside the sample loop (no 64-bit literal operands on this ISA) -- a sixth of the loop's VALU
-// slots; as LDS words they are broadcast ds_read_b64, which do not take a VALU slot.
-__device__ const double POWF_CONST[12] = {0x1.27616c9496e0bp-2, -0x1.71969a075c67ap-2, 0x1.ec70a6ca7baddp-2, -0x1.7154748bef6c8p-1, 0x1.71547652ab82bp+0,
-                                          0x1.fffffffd1d571p+6, -150.0, -149.0, 0x1.8p+47, 0x1.c6af84b912394p-5, 0x1.ebfce50fac4f3p-3, 0x1.62e42ff0c52d6p-1};
-#define RT_POW_TAB 76
+#define RT_POW_TAB 64
 // The tables live in LDS for the kernel (64 x 8 B: INVC[16] | LOGC[16] | EXP2_TAB[32]): a lookup is a ds_read_b64, not a global load on the
 // critical path of every sample.  The function has NO divergent branch: the one common special case (cosphi = +0 with a positive finite
 // shininess: the answer is +0) and the three range answers of the main path are selects; everything else e_powf.c answers without
@@ -3275,29 +3270,29 @@ __device__ __forceinline__ float pow_shininess(const float x, const float y, con
     const double r = __builtin_fma(z, tab[i], -1.0);
     const double y0 = tab[16u + i] + static_cast<double>(k);
     const double r2 = r * r;
-    const double yy = __builtin_fma(tab[64], r, tab[65]);
-    const double p = __builtin_fma(tab[66], r, tab[67]);
+    const double yy = __builtin_fma(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
+    const double p = __builtin_fma(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
     const double r4 = r2 * r2;
-    double q = __builtin_fma(tab[68], r, y0);
+    double q = __builtin_fma(0x1.71547652ab82bp+0, r, y0);
     q = __builtin_fma(p, r2, q);
     const double logx = __builtin_fma(yy, r4, q);
     const double ylogx = static_cast<double>(y) * logx;
     // |y * log2(x)| >= 126: __math_oflowf / __math_uflowf / __math_may_uflowf, else the ordinary path (also for -149 <= y log2 x <= -126)
     const bool big = ((static_cast<unsigned long long>(__double_as_longlong(ylogx)) >> 47) & 0xffffull) >= 0x80bfull;
-    const bool r_of = big && (ylogx > tab[69]);
-    const bool r_uf = big && !r_of && (ylogx <= tab[70]);
-    const bool r_mu = big && !r_of && !r_uf && (ylogx < tab[71]);
+    const bool r_of = big && (ylogx > 0x1.fffffffd1d571p+6);
+    const bool r_uf = big && !r_of && (ylogx <= -150.0);
+    const bool r_mu = big && !r_of && !r_uf && (ylogx < -149.0);
     // exp2_inline
-    const double shift = tab[72];
+    const double shift = 0x1.8p+47;
     double kd = ylogx + shift;
     const unsigned long long ki = static_cast<unsigned long long>(__double_as_longlong(kd));
     kd -= shift;
     const double rr = ylogx - kd;
     const unsigned long long t = static_cast<unsigned long long>(__double_as_longlong(tab[32u + static_cast<uint32_t>(ki & 31ull)])) + (ki << 47);
     const double sc = __longlong_as_double(static_cast<long long>(t));
-    const double zz = __builtin_fma(tab[73], rr, tab[74]);
+    const double zz = __builtin_fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
     const double rr2 = rr * rr;
-    double yv = __builtin_fma(tab[75], rr, 1.0);
+    double yv = __builtin_fma(0x1.62e42ff0c52d6p-1, rr, 1.0);
     yv = __builtin_fma(zz, rr2, yv);
     yv = yv * sc;
     float res = static_cast<float>(yv);
@@ -3319,9 +3314,11 @@ __device__ __forceinline__ float fresnel_term(float ix, float iy, float iz, floa
     return (Rs * Rs + Rp * Rp) / 2;
 }
 
-// 4 waves per SIMD (128 VGPRs, 88 B of scratch) instead of 3 (149 VGPRs): -7 % on the 576k-item cube frame
+// waves per SIMD: 3 (149 VGPRs) -> 4 (128) was -7 % on the 576k-item cube frame in round 1; 4 -> 5 (96 VGPRs, 20 B of scratch) is another -4 % now that
+// the sample loop is leaner (round 3, same-box A/B: k_shade 0.192 -> 0.185 ms).  (The powf coefficients stay literals: kept in LDS they are
+// hoisted into 24 VGPRs, which is +1 % at four waves and 112 B of scratch at five.)
 #ifndef RT_SHADE_WPE
-#define RT_SHADE_WPE 4
+#define RT_SHADE_WPE 5
 #endif
 #define RT_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(RT_SHADE_WPE, 8)))
 // ---- phongShade / getInterpolatedNormal / the material dispatch of traceRay, shared by k_shade (visibility words from the shadow kernels) and
@@ -3421,7 +3418,7 @@ __device__ __forceinline__ uint32_t material_dispatch(const ShadeHit &H, const b
 __device__ __forceinline__ void pow_tables_to_lds(double *s_pow) {
     if (threadIdx.x < RT_POW_TAB) {
         const uint32_t ti = threadIdx.x;
-        s_pow[ti] = ti < 16u ? POWF_LOG2_INVC[ti] : (ti < 32u ? POWF_LOG2_LOGC[ti - 16u] : (ti < 64u ? __longlong_as_double(static_cast<long long>(POWF_EXP2_TAB[ti - 32u])) : POWF_CONST[ti - 64u]));
+        s_pow[ti] = ti < 16u ? POWF_LOG2_INVC[ti] : (ti < 32u ? POWF_LOG2_LOGC[ti - 16u] : __longlong_as_double(static_cast<long long>(POWF_EXP2_TAB[ti - 32u])));
     }
     __syncthreads();
 }
@@ -3438,7 +3435,7 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DNode *__rest
                                                const int lslots, const ShadeItem *__restrict__ items, Control *__restrict__ ctl,
                                                const unsigned long long *__restrict__ vis, float4 *__restrict__ rec,
                                                float *__restrict__ fres, RayItem *__restrict__ rays_out) {
-    __shared__ double s_pow[RT_POW_TAB];       // powf tables: INVC[16] | LOGC[16] | EXP2_TAB[32] (bit patterns) | coefficients and thresholds [12]
+    __shared__ double s_pow[RT_POW_TAB];       // powf tables: INVC[16] | LOGC[16] | EXP2_TAB[32] (bit patterns)
     pow_tables_to_lds(s_pow);
     const int lane = threadIdx.x & 63;
     const ShardMap imap = shard_map(ctl->n_items[level], lane, F.item_cap, 1u, 64u);      // groups of 64 items, shard after shard
