@@ -64,8 +64,8 @@ COST = {
     "unit_stack": 200,
     "unit_trace": 260,           # trace kernels per unit (a tile of 64 rays, or a leaf task): ray generation (Camera::screenToWorld in double), root tests, records / compaction
     "beam": 700,                 # k_beam per (tile of 64 hits, light) on a flat scene: items, wave min / max, planes, one leaf (chunk test + per-triangle test)
-    "shade_sample": 215,         # k_shade per (tile of 64 hits, sample): light direction + reflection normalised (2 x sqrt + 6 IEEE divisions), glibc powf in double (branch-free: range and special answers are selects)
-    "shade_tile": 500,           # k_shade per tile: items, interpolated normal, eye vector, material, record
+    "shade_sample": 170,         # k_shade per (tile of 64 hits, sample): light direction + reflection normalised (2 x sqrt, the three quotients of each share one reciprocal), glibc powf in double (branch-free: range and special answers are selects)
+    "shade_tile": 1100,          # k_shade per tile: items, interpolated normal, eye vector, material, record; flat scenes: the child ray against the root leaf
 }
 
 
@@ -156,12 +156,15 @@ def clock_independent(kernels, pick):
     cyc = sum(v["gpu_cycles"] for v in sel.values())
     out = {"frac_clock_independent": round(insts / cyc / N_SIMDS / 0.5, 4),
            "clock_independent_source": "sum SQ_INSTS_VALU / sum (GRBM_GUI_ACTIVE / 8) / 1024 SIMDs / 0.5 per cycle over the level-0 launches of the group"}
-    act = [v for v in sel.values() if v.get("active_inst_valu") and v.get("busy_cycles")]
+    act = [v for v in sel.values() if v.get("active_inst_valu") and v.get("wave_cycles")]
     if act:
-        # SQ_ACTIVE_INST_VALU counts quad-cycles in which a wave executes a VALU instruction, SQ_BUSY_CYCLES the quad-cycles the SQs are busy (per SE): their
-        # ratio over the number of waves per SIMD that can issue is the time share of VALU execution -- double-rate FP64 work shows up here, not in the count
-        out["valu_active_over_busy"] = round(sum(v["active_inst_valu"] for v in act) / sum(v["busy_cycles"] for v in act), 4)
-        out["valu_active_source"] = "SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES (second rocprofv3 --pmc pass of tools/valu.sh)"
+        # second PMC pass (tools/valu.sh): SQ_ACTIVE_INST_VALU = quad-cycles in which a wave executes a VALU instruction, SQ_WAVE_CYCLES = quad-cycles of wave
+        # lifetime.  Their ratio is the share of its lifetime a wave spends executing VALU work; ACTIVE over the instruction count is the execution time per
+        # instruction as the hardware counts it (1.0 = 4 cycles; half-rate FP64 work would push it up) -- counters, not estimates
+        a, w, n = sum(v["active_inst_valu"] for v in act), sum(v["wave_cycles"] for v in act), sum(v["valu_wave_instructions"] for v in act)
+        out["wave_lifetime_share_executing_valu"] = round(a / w, 4)
+        out["valu_active_quadcycles_per_instruction"] = round(a / n, 4)
+        out["valu_active_source"] = "SQ_ACTIVE_INST_VALU, SQ_WAVE_CYCLES, SQ_BUSY_CYCLES (second rocprofv3 --pmc pass of tools/valu.sh)"
     return out
 
 

@@ -103,6 +103,7 @@ struct rt_ctx {
     float *d_offsets = nullptr;  // RT_LIGHT_SPHERE sample offsets of the last eager call (a captured graph owns a copy of its own: rt_graph)
     size_t cap_offsets = 0;
     uint32_t frame_launches = 0;               // device operations (kernel launches + memsets) the last run_frame enqueued
+    int frame_wide_levels = 0;                 // levels of the last frame that ran the per-level kernel groups (the deeper ones went to k_deep)
     hipStream_t last_frame_stream = nullptr;   // stream of the most recent eager frame (it may still read d_offsets)
     float *d_rgb = nullptr;      // staging for rt_render (host output)
     int32_t *d_hit = nullptr;
@@ -764,6 +765,7 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
     ++nl, launch_resolve(c->cus * 8, st, Fr, c->d_rec, c->d_fres, d_rgb, d_u8);
     if (timed) HIPCHK(c, hipEventRecord(event_at(c, ev++), st));
     c->frame_launches = nl;
+    c->frame_wide_levels = wide_levels;
     HIPCHK(c, hipGetLastError());
     return RT_OK;
 }
@@ -785,9 +787,10 @@ static rt_status sum_frame_times(rt_ctx *c, size_t ev, int levels_run, rt_stats 
     }
     if (!lean) { HIPCHK(c, hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1])); out->ms_resolve += ms; }
     HIPCHK(c, hipEventElapsedTime(&ms, c->events[first], c->events[ev + 1])); out->ms_total += ms;
-    out->launches_trace += static_cast<uint32_t>(levels_run);
-    out->launches_shadow += static_cast<uint32_t>(levels_run);
-    out->launches_shade += static_cast<uint32_t>(levels_run);
+    const uint32_t wide = static_cast<uint32_t>(c->frame_wide_levels > 0 && c->frame_wide_levels < levels_run ? c->frame_wide_levels : levels_run);
+    out->launches_trace += wide;
+    out->launches_shadow += wide;
+    out->launches_shade += wide;
     out->launches_total = c->frame_launches;
     return RT_OK;
 }

@@ -1,4 +1,4 @@
-"""The bench line the driver records: the committed run of `python bench.py` (profiles/r02_bench_default.json, produced on an MI355X)
+"""The bench line the driver records: the committed run of `python bench.py` (profiles/r03_bench_default.json, produced on an MI355X)
 carries every field of the bench contract, with the types and the internal consistency the contract asks for.  CPU only: nothing is
 executed, the JSON a real run printed is checked."""
 import csv
@@ -8,7 +8,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEFAULT = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_default.json")))
+DEFAULT = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_default.json")))
 
 
 def records():
@@ -33,7 +33,8 @@ def test_headline_has_the_contract_fields():
 
 
 def rooflines(d):
-    """`roofline` is the kernel group that takes most of the frame (shadow group or k_shade); the other one is kept beside it"""
+    """`roofline` is the kernel group that takes most of the frame (shadow group or k_shade); the other one is kept beside it (the trace group
+    has a record of its own: test_trace_group_walked_rays_launches_and_cpu_ratios)"""
     out = [d["roofline"]]
     for k in ("roofline_shadow", "roofline_shade"):
         if k in d:
@@ -69,22 +70,52 @@ def test_every_record_is_consistent_and_its_roofline_physical(name, d):
         # PMC constants: quoted (then physical too) or explicitly null
         ev = r["executed_valu"]
         assert ev["constant"] is True and (ev["frac"] is None or r["frac"] * 0.5 <= ev["frac"] <= 1.0)
+        if ev["frac"] is not None:
+            # the clock-independent form beside the per-ns one: instructions / GPU cycles / 1024 SIMDs / 0.5 per cycle
+            assert 0.0 < ev["frac_clock_independent"] <= 1.0 and "GRBM_GUI_ACTIVE" in ev["clock_independent_source"]
+            if r["group"] == "shade":
+                assert 0.0 < ev["wave_lifetime_share_executing_valu"] <= 1.0 and ev["valu_active_quadcycles_per_instruction"] >= 0.9
         assert r["traffic"] is None or (r["traffic"] > 0 and 0.0 < r["hbm_frac"] <= 1.0)
         assert "HIP events" in r["timing_source"]
     c = d["cpu_baseline"]
     assert c["unit"] == "Mrays/s" and c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
 
 
+@pytest.mark.parametrize("name,d", records())
+def test_trace_group_walked_rays_launches_and_cpu_ratios(name, d):
+    """Round-3 evidence fields: a roofline record for the trace group whose counters carry the trace region's own names; the rays actually formed and
+    walked beside the queries resolved; launches per frame; both CPU ratios with their hosts."""
+    t = d["roofline_trace"]
+    assert t["group"] == "trace" and t["bound"] == "valu" and t["peak"] == 0.967
+    w = t["work"]["trace"]
+    assert set(w) >= {"tri_steps_lanes_rays", "tri_steps_lanes_triangles", "box_steps_stack_walk", "units", "tri_cone_tests"}
+    assert not any(k.startswith("beam") or k.startswith("shaft") for k in w)            # no shadow-kernel names on the trace region
+    assert w["units"] > 0 and 0.0 < t["frac"] <= 1.0 and t["useful_frac"] <= t["frac"]
+    assert abs(t["achieved"] - t["modelled_valu_wave_instructions_per_frame"]["total"] / (t["ms_per_frame"]["trace"] * 1e6) / 1024) <= 2e-3 * max(1.0, t["achieved"])
+    # queries resolved (SURVEY 8(d)) vs rays actually walked
+    assert 0 < d["rays_walked_per_frame"] <= d["rays_per_frame"]
+    assert abs(d["Mrays_walked_per_s"] - d["rays_walked_per_frame"] / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-3 * d["Mrays_walked_per_s"]
+    if name == "cube headline":
+        assert d["rays_walked_per_frame"] < 0.2 * d["rays_per_frame"]       # the beam test decides most sample segments without forming them
+        assert d["launches_per_frame"] <= 12                                # memset + 4 + 4 + k_deep + resolve (22 before round 3)
+    assert d["launches_per_frame"] >= 6
+    ratios = d["cpu_baseline"]["ratios"]
+    assert ratios["vs_port_same_host"]["value"] == d["speedup_vs_cpu_port"] and "this host" in ratios["vs_port_same_host"]["cpu"]
+    if "cfg4" not in name:
+        r = ratios["vs_reference_as_surveyed"]
+        assert r["value"] > ratios["vs_port_same_host"]["value"] and "another host" in r["cpu"]
+
+
 @pytest.mark.parametrize("scene,kernel", [("cube", "k_shadow<false, true, false>"), ("dodge", "k_shadow_shaft"), ("wavy", "k_shadow_shaft")])
 def test_rocprof_kernel_stats_agree_with_the_event_times(scene, kernel):
-    """profiles/r02_<scene>_kernel_stats.csv (rocprofv3 --kernel-trace --stats over bench.py) against the HIP-event time of the SAME run
-    (profiles/r02_bench_<scene>_under_rocprof.json): the shadow group's average duration per frame agrees within 10 % (+ 4 us per launch of the
+    """profiles/r03_<scene>_kernel_stats.csv (rocprofv3 --kernel-trace --stats over bench.py) against the HIP-event time of the SAME run
+    (profiles/r03_bench_<scene>_under_rocprof.json): the shadow group's average duration per frame agrees within 10 % (+ 4 us per launch of the
     group for the gaps the event interval contains)."""
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"r02_{scene}_kernel_stats.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"r03_{scene}_kernel_stats.csv"))))
     # the shadow GROUP of a level: beam test + walking launch (+ leaf-task launch); "k_shadow<true, ..." are the COUNT variants of the statistics frames
     shadow = [r for r in rows if ("k_shadow" in r["Name"] or "k_beam" in r["Name"]) and "k_shadow<true" not in r["Name"]]
     assert any(kernel in r["Name"] for r in shadow)
-    bench = json.load(open(os.path.join(ROOT, "profiles", f"r02_bench_{scene}_under_rocprof.json")))
+    bench = json.load(open(os.path.join(ROOT, "profiles", f"r03_bench_{scene}_under_rocprof.json")))
     rs = bench["roofline"] if bench["roofline"]["group"] == "shadow" else bench["roofline_shadow"]
     # one WALKING launch per level (not the beam test, not the leaf-task launches k_shadow_shaft<true, ...> / k_shadow<false, false, true>)
     walking = [r for r in shadow if "k_shadow" in r["Name"] and "k_shadow_shaft<true" not in r["Name"] and "k_shadow<false, false, true>" not in r["Name"]]
