@@ -80,7 +80,8 @@ struct rt_ctx {
     size_t cap_lit = 0, cap_best = 0;
     ContTask *d_tasks[2] = {nullptr, nullptr};   // continuation queues of k_shadow (tree scenes)
     uint32_t task_cap = 1u << 21;
-    uint32_t trace_budget = 1000u;              // leaves above this estimated cost (VALU instructions) become tasks (0 = off)
+    uint32_t trace_budget = 500u;               // leaves above this estimated cost (VALU instructions) become tasks (0 = off); round 3 sweep after the task
+                                                // counters were sharded: dodge trace 0.250 / 0.239 / 0.243 ms at 1000 / 500 / 250
     uint32_t group_budget = 4u;                 // groups a trace unit pops before it hands the rest of its stack to the task launch (RT_GROUP_BUDGET, 0 = never)
     uint32_t shadow_budget = 3000u;
     bool beam_trees = false;
@@ -90,7 +91,10 @@ struct rt_ctx {
     uint32_t shaft_budget_deep = 3000u;   // ... but the bounce levels have few units and a heavy tail: their big leaves do go to a leaf-task launch (cfg4 29.2 -> 28.3 ms)
     int stage_mult = 2;                         // grid multiplier of the main k_stage launches (RT_STAGE_MULT): twice the resident grid lets
                                                 // blocks of sky tiles retire early and evens out the object tiles (dodge trace 0.278 -> 0.254 ms)
-    uint32_t task_target = 0u;                  // estimated cost of one leaf-task piece (0 = same as the budget)
+    uint32_t task_target = 0u;                  // estimated cost of one leaf-task piece (0 = same as the budget); RT_TASK_TARGET, else set per scene at upload
+    uint32_t trace_target = 1000u;              // ... of the trace stages: 1000 on small scenes, 4000 on big ones (cfg4 has > 130 k tasks per stage: trace 2.12 -> 1.76 ms;
+                                                // dodge, 9 k tasks: 0.245 vs 0.256 ms the other way) -- by leaf references, see rt_upload_scene
+    bool task_target_env = false;
     float4 *d_rec = nullptr;
     float *d_fres = nullptr;
     Control *d_ctl = nullptr;
@@ -159,7 +163,7 @@ extern "C" rt_status rt_create(rt_ctx **out, int device) {
     if (const char *sg = std::getenv("RT_STAGED_TRACE")) c->staged_trace = std::atoi(sg) != 0;
     if (const char *sm = std::getenv("RT_STAGE_MULT")) { const int v = std::atoi(sm); if (v >= 1 && v <= 8) c->stage_mult = v; }
     if (const char *tc = std::getenv("RT_TASK_CAP")) { const long v = std::atol(tc); if (v >= 64 && v <= (1l << 24)) c->task_cap = static_cast<uint32_t>(v); }
-    if (const char *tt = std::getenv("RT_TASK_TARGET")) c->task_target = static_cast<uint32_t>(std::atoi(tt));
+    if (const char *tt = std::getenv("RT_TASK_TARGET")) { c->task_target = static_cast<uint32_t>(std::atoi(tt)); c->task_target_env = true; }
     if (const char *tb = std::getenv("RT_TRACE_BUDGET")) c->trace_budget = static_cast<uint32_t>(std::atoi(tb));
     if (const char *gb = std::getenv("RT_GROUP_BUDGET")) c->group_budget = static_cast<uint32_t>(std::atoi(gb));
     if (const char *gm = std::getenv("RT_GRID_MULT")) {          // tuning knob: grid = CUs x residency x mult
@@ -530,14 +534,17 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
 #ifdef RT_UNIT_HIST
     {   // (leaked at rt_destroy: diagnostic build)
         static uint32_t *dbg_buf = nullptr;
-        if (!dbg_buf && hipMalloc(reinterpret_cast<void **>(&dbg_buf), static_cast<size_t>(RT_UNIT_DBG_WORDS) * sizeof(uint32_t)) == hipSuccess)
-            (void)hipMemset(dbg_buf, 0, static_cast<size_t>(RT_UNIT_DBG_WORDS) * sizeof(uint32_t));
+        if (!dbg_buf && hipMalloc(reinterpret_cast<void **>(&dbg_buf), (static_cast<size_t>(RT_UNIT_DBG_WORDS) + RT_UNIT_DBG_SHAFT) * sizeof(uint32_t)) == hipSuccess)
+            (void)hipMemset(dbg_buf, 0, (static_cast<size_t>(RT_UNIT_DBG_WORDS) + RT_UNIT_DBG_SHAFT) * sizeof(uint32_t));
         c->S.dbg = dbg_buf;
     }
 #endif
     c->S.beam = (no_cull || std::getenv("RT_NO_BEAM") != nullptr) ? 0 : 1;
+    c->S.beam_budget = 1024;
+    if (const char *bb = std::getenv("RT_BEAM_BUDGET")) { const int v = std::atoi(bb); if (v >= 1 && v <= (1 << 20)) c->S.beam_budget = v; }
     if (sc->n_nodes >= (1u << 28)) { c->err = "rt_upload_scene: more than 2^28 nodes"; return RT_ERR_UNSUPPORTED; }
     c->flat = (sc->nodes[0].count_flags & RT_NODE_LEAF) && (sc->nodes[0].count_flags & 0x7fffffffu) <= 64u;
+    { const uint32_t t = sc->n_face_refs / 256u; c->trace_target = t < 1000u ? 1000u : (t > 4000u ? 4000u : t); }
     query_occupancy(c->flat, &c->occ_trace_primary, &c->occ_trace_rays, &c->occ_shadow, &c->occ_shaft, &c->occ_shade);
     // k_trace uses static tile striding: with more than ~4 blocks/CU a wave owns so few tiles (32,400 tiles at 1080p)
     // that heavy object tiles no longer average out (measured 0.26 ms at 4 blocks/CU vs 0.38 ms at 7-8)
@@ -716,7 +723,7 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
             for (int stage = 0; stage < 2; ++stage) {
                 const uint32_t q0 = static_cast<uint32_t>(stage);
                 ++nl, launch_stage(prim, count, stage, false, tgrid * c->stage_mult, st, c->S, c->d_cam, L, F, level, lslots, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
-                             hit_l, t_l, c->d_best, c->d_lit, TaskQueues{nullptr, B ? c->d_tasks[stage] : nullptr, 0u, q0, cap, B, c->task_target, count ? 0u : c->group_budget});
+                             hit_l, t_l, c->d_best, c->d_lit, TaskQueues{nullptr, B ? c->d_tasks[stage] : nullptr, 0u, q0, cap, B, c->task_target_env ? c->task_target : c->trace_target, count ? 0u : c->group_budget});
                 if (B != 0u)
                     ++nl, launch_stage(prim, false, stage, true, tgrid, st, c->S, c->d_cam, L, F, level, lslots, c->d_rays[level & 1], c->d_items, c->d_ctl, rec_l,
                                  hit_l, t_l, c->d_best, c->d_lit, TaskQueues{c->d_tasks[stage], nullptr, q0, 0u, cap, 0u});
@@ -820,11 +827,11 @@ static rt_status fill_stats(rt_ctx *c, hipStream_t st, const DFrame &F, int leve
 #ifdef RT_UNIT_HIST
     if (!counted && c->S.dbg != nullptr) {
         if (const char *dump = std::getenv("RT_UNIT_DUMP")) {
-            std::vector<uint32_t> hbuf(RT_UNIT_DBG_WORDS);
+            std::vector<uint32_t> hbuf(static_cast<size_t>(RT_UNIT_DBG_WORDS) + RT_UNIT_DBG_SHAFT);
             HIPCHK(c, hipMemcpy(hbuf.data(), c->S.dbg, hbuf.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
             if (FILE *f = std::fopen(dump, "wb")) { std::fwrite(hbuf.data(), sizeof(uint32_t), hbuf.size(), f); std::fclose(f); }
         }
-        HIPCHK(c, hipMemset(c->S.dbg, 0, static_cast<size_t>(RT_UNIT_DBG_WORDS) * sizeof(uint32_t)));
+        HIPCHK(c, hipMemset(c->S.dbg, 0, (static_cast<size_t>(RT_UNIT_DBG_WORDS) + RT_UNIT_DBG_SHAFT) * sizeof(uint32_t)));
     }
 #endif
 #ifdef RT_PROFILE

@@ -132,12 +132,14 @@ struct DScene {
     const float *bad_leaves;           // boxes (min, max) of the leaves that hold a chunk which may never be culled (k_beam tests them per hit)
     uint32_t n_bad_leaves;             // 0xffffffff: too many for the per-hit test -- such a chunk then blocks every beam that meets it
     int32_t beam;                      // k_beam before the shadow kernels: whole tiles of 64 lit hits whose sample rays nothing can block; RT_NO_BEAM=1 turns it off
+    int32_t beam_budget;               // k_beam: group steps + chunk batches + chunks a beam may spend before it leaves its hits to the shadow units (RT_BEAM_BUDGET)
     int32_t shaft;                     // k_shadow on tree scenes: shaft-culled group walk (rt_kernels.hip, shaft_walk); RT_NO_SHAFT=1 turns it off
 #ifdef RT_UNIT_HIST
     uint32_t *dbg;                     // diagnostic build only: per-unit / per-wave records of the trace stages (rt_capi.cpp: RT_UNIT_DUMP)
 #endif
 };
-#define RT_UNIT_DBG_WORDS (4u * 65536u * 8u + 4u * 16384u * 4u)
+#define RT_UNIT_DBG_WORDS (4u * 65536u * 8u + 4u * 16384u * 4u)          // trace-stage unit and wave records ...
+#define RT_UNIT_DBG_SHAFT (65536u * 16u)                                   // ... followed by the unit records of the level-0 k_shadow_shaft launch
 
 struct DCam {
     float center[3];

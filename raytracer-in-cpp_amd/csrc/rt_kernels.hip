@@ -402,6 +402,13 @@ __device__ uint32_t g_prof_base = 0u;       // step counters of the launch in fl
 #else
 #define RT_PROF_ADD(lane, idx, val) do { } while (0)   // RT_PROFILE alone: only the per-unit cycle histogram (undistorted)
 #endif
+#elif defined(RT_UNIT_HIST)
+// RT_UNIT_HIST build: the step counters of the unit in flight, per wave in LDS (plain adds by lane 0); k_shadow_shaft copies them into its unit record.
+// slots: 0 groups (88) | 1 children surviving the shaft test (90) | 2 children hit by some ray (91) | 3 chunk batches (92) | 4 chunks with work (95) |
+//        5 per-triangle shaft tests (70) | 6 ray-mode triangle steps (0) | 7 (ray, chunk) triangle steps (2)
+__shared__ uint32_t g_uh[RT_WAVES * 8];
+#define RT_UH_SLOT(idx) ((idx) == 88 ? 0 : (idx) == 90 ? 1 : (idx) == 91 ? 2 : (idx) == 92 ? 3 : (idx) == 95 ? 4 : (idx) == 70 ? 5 : (idx) == 0 ? 6 : (idx) == 2 ? 7 : -1)
+#define RT_PROF_ADD(lane, idx, val) do { if (RT_UH_SLOT(idx) >= 0 && (lane) == 0) g_uh[(threadIdx.x >> 6) * 8 + (RT_UH_SLOT(idx) >= 0 ? RT_UH_SLOT(idx) : 0)] += static_cast<uint32_t>(val); } while (0)
 #else
 #define RT_PROF_ADD(lane, idx, val) do { } while (0)
 #endif
@@ -2714,6 +2721,10 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         pclk.to(6);
         const unsigned long long unit_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef RT_UNIT_HIST
+        const unsigned long long uh_t0 = static_cast<unsigned long long>(clock64());
+        if (lane < 8) g_uh[wave * 8 + lane] = 0u;
+#endif
         RT_PROF_ADD(lane, 13, 1);
         uint32_t unit = work;
         uint32_t t_node = 0u, t_cb = 0u, t_ce = 0u;
@@ -2801,6 +2812,14 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         }
 #ifdef RT_PROFILE
         pclk.to(7);
+#endif
+#ifdef RT_UNIT_HIST
+        if (!CONT && !TASKS && level == 0 && S.dbg != nullptr && work < 65536u) {
+            // unit record (kernel block 4 of the debug buffer): cycles / 16, then the eight step counters of g_uh -- 9 words of a 16-word slot
+            const unsigned long long dtu = (static_cast<unsigned long long>(clock64()) - uh_t0) >> 4;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 9) S.dbg[RT_UNIT_DBG_WORDS + static_cast<size_t>(work) * 16u + static_cast<uint32_t>(lane)] = lane == 0 ? static_cast<uint32_t>(dtu) : g_uh[wave * 8 + lane - 1];
+        }
 #endif
 #ifdef RT_PROFILE
         if (lane == 0 && g_prof) {      // per-unit duration histogram: prof[560 + log2(10 ns ticks)], max prof[559]
@@ -3050,7 +3069,7 @@ __device__ __forceinline__ void beam_tile(const BeamCtx &B, const DScene &S, con
             __builtin_amdgcn_wave_barrier();
             // ---- the walk: groups of children by content box, leaves chunk by chunk, triangle by triangle
             bool blocked = false;
-            int sp = 0, budget = RT_BEAM_BUDGET;
+            int sp = 0, budget = S.beam_budget;
             if (root.count_flags & RT_NODE_LEAF) {
                 blocked = (root.count_flags & 0x7fffffffu) != 0u &&
                           beam_leaf(uniform_u32(root.first), uniform_u32(root.count_flags) & 0x7fffffffu, uniform_u32(root.pad[0]), tris, chunks, lane, shaft, rec, SC, per_item, budget);
@@ -3085,7 +3104,7 @@ __device__ __forceinline__ void beam_tile(const BeamCtx &B, const DScene &S, con
                     }
                 }
             }
-            RT_PROF_ADD(lane, 76, 1); RT_PROF_ADD(lane, 77, blocked ? 0 : 1); RT_PROF_ADD(lane, 80, blocked ? 0 : RT_BEAM_BUDGET - budget); RT_PROF_ADD(lane, 81, budget < 0 ? 1 : 0);
+            RT_PROF_ADD(lane, 76, 1); RT_PROF_ADD(lane, 77, blocked ? 0 : 1); RT_PROF_ADD(lane, 80, blocked ? 0 : S.beam_budget - budget); RT_PROF_ADD(lane, 81, budget < 0 ? 1 : 0);
             if (brake && lane == 0) { atomicAdd(&yield[0], 1u); if (!blocked) atomicAdd(&yield[1], 1u); }
             // the leaves with a chunk that may never be culled (degenerate triangles whose computed barycentrics are noise): can a ray to
             // THIS hit -- or its continuation behind the hit -- enter the leaf's own box?  Lane-local shaft of (S, h): if the padded box is

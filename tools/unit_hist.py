@@ -46,3 +46,24 @@ for k in range(4):
     A = np.column_stack([u[:, 1:7].astype(np.float64), np.ones(len(u))])
     coef, *_ = np.linalg.lstsq(A, cyc, rcond=None)
     print("   least-squares cycles per: group %.0f leaf %.0f task-atomic %.0f ray-mode-tri %.0f tri-mode-step %.0f chunk-test %.0f unit %.0f" % tuple(coef))
+
+# ---- the level-0 k_shadow_shaft launch (tree scenes, > 32 samples)
+off = 4 * 65536 * 8 + 4 * 16384 * 4
+if raw.size >= off + 65536 * 16:
+    Sh = raw[off:off + 65536 * 16].reshape(65536, 16)
+    u = Sh[Sh[:, 0] > 0]
+    if len(u):
+        cyc = u[:, 0].astype(np.float64) * 16
+        names = ["groups", "shaft-survivors", "children-hit", "chunk-batches", "chunks-with-work", "tri-shaft-tests", "ray-mode-tri-steps", "(ray,chunk)-steps"]
+        print(f"== k_shadow_shaft level 0: sampled units {len(u)}; kcycles mean {cyc.mean()/1e3:.1f} p50 {np.percentile(cyc,50)/1e3:.1f} p90 {np.percentile(cyc,90)/1e3:.1f} p99 {np.percentile(cyc,99)/1e3:.1f} max {cyc.max()/1e3:.1f}")
+        print("   mean steps per unit:", {n: round(float(u[:, 1 + i].mean()), 2) for i, n in enumerate(names)})
+        A = np.column_stack([u[:, 1:9].astype(np.float64), np.ones(len(u))])
+        coef, *_ = np.linalg.lstsq(A, cyc, rcond=None)
+        print("   least-squares cycles per step:", {n: int(c) for n, c in zip(names + ["unit"], coef)})
+        share = {n: round(float(coef[i] * u[:, 1 + i].sum() / cyc.sum()), 3) for i, n in enumerate(names)}
+        share["unit"] = round(float(coef[8] * len(u) / cyc.sum()), 3)
+        print("   share of the unit time:", share)
+        for lo, hi in ((0, 50), (50, 90), (90, 99), (99, 100)):
+            a, b = np.percentile(cyc, lo), np.percentile(cyc, hi)
+            m = (cyc >= a) & (cyc <= b)
+            print(f"   units p{lo}-p{hi}: share of time {cyc[m].sum()/cyc.sum():.2f}, mean groups {u[m,1].mean():.1f} children-hit {u[m,3].mean():.1f} chunk-batches {u[m,4].mean():.1f} tri-shaft {u[m,6].mean():.1f} steps {u[m,7].mean()+u[m,8].mean():.1f}")
