@@ -371,6 +371,8 @@ def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, c
                 g.launch(cam, stream.cuda_stream)
             torch.cuda.synchronize(dev)
             rec["graph_replay_ms_per_frame_same_camera"] = round((time.perf_counter() - tg0) / len(cams) * 1e3, 4)
+            rec["graph_replay_note"] = ("yaw path = BASELINE cfg5's camera (2 pi / 120 per frame about the camera's own centre): the object is in view on roughly a fifth of the "
+                                        "frames and the others render background only, so its mean is NOT comparable with ms_per_step; same_camera replays the headline view")
             g.close()
         except Exception as e:            # noqa: BLE001 -- the graph path is an extra; never let it take the bench line down
             rec["graph_replay_ms_per_frame_yaw_path"] = f"failed: {e}"

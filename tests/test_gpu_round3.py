@@ -225,3 +225,43 @@ def test_deep_levels_in_one_launch_equal_the_wide_kernels_and_the_oracle(rt, ora
     if which == "mixed":
         assert ost.rays_bounce > 0
     osc.close(); hs.close()
+
+
+# ------------------------------------------------------------------------------------------ BASELINE cfg5 on one GPU, full size
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["cube.obj", "dodgeColorTest.obj"])
+def test_cfg5_animation_120_frames_1080p_graph_replay(rt, oracle, scene):
+    """BASELINE cfg5's per-GPU share at full size: 120 frames at 1920 x 1080, depth 4, 64 samples, the fly camera yawing 2 pi / 120 per frame
+    (flycamera.hpp:166-191), ONE captured hipGraph replayed per frame.  Every frame is produced without an error; frames 0, 7, 60 and 113 (the object in view at 0, 7 and 113; the camera looks away from it at 60) equal the
+    oracle's frame of that camera bit for bit (float RGB) and their 8-bit rows equal writePPMImage's quantisation; frame 120 (yaw 2 pi in
+    float) reproduces the eager frame of the same camera."""
+    w, h, frames = 1920, 1080, 120
+    path = os.path.join(SCENES, scene)
+    hs = rt.HostScene(path, 1000, 15)
+    ctx = rt.Context(0)
+    ctx.upload(hs)
+    L = rt.make_lights(area=True, usteps=8, vsteps=8)
+    p = rt.make_params(w, h, 4)
+    out = rt.hipmem.DeviceBuffer(h * w * 3 * 4)
+    out8 = rt.hipmem.DeviceBuffer(h * w * 3)
+    g = rt.FrameGraph(ctx, L, p, out.address, out8.address)
+    osc = oracle.load_scene(path)
+    shas = []
+    for f in range(frames + 1):
+        yaw = float(np.float32(2.0 * np.pi * f / frames))
+        g.launch(rt.default_camera(w, h, yaw))
+        if f in (0, 7, 60, 113, frames):
+            g.stats()                                   # synchronises
+            got = out.to_numpy(np.float32, (h, w, 3))
+            got8 = out8.to_numpy(np.uint8, (h, w, 3))
+            shas.append(hashlib.sha256(got8.tobytes()).hexdigest())
+            if f < frames:
+                ref, _, _ = osc.render(oracle.camera(w, h, yaw), oracle.lights(area=True, usteps=8, vsteps=8), w, h, max_depth=4, threads=8)
+                assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (scene, f, float(np.abs(got - ref).max()))
+                assert np.array_equal(got8, np.clip(oracle.quantise(ref), 0, 255).astype(np.uint8))
+            else:
+                eager, _ = render_gpu(rt, ctx, rt.default_camera(w, h, yaw), L, w, h, 4)
+                assert np.array_equal(got.view(np.uint32), eager.view(np.uint32))
+    st = g.stats()
+    assert st.total_rays() > 0 and len(set(shas[:4])) == 4          # the camera really moved
+    g.close(); out.free(); out8.free(); osc.close(); ctx.close(); hs.close()
