@@ -44,6 +44,8 @@ for sc in cfg:
             count_arg = {"k_shadow": 0, "k_trace": 1, "k_stage": 1}.get(k.split("::")[-1].split("<")[0])
             if count_arg is not None and args and args[count_arg] == "true":
                 continue                                    # counting-pass variants
+            if k.split("::")[-1].startswith("k_shade<") and args[1] == "false" and any(kk.split("::")[-1].startswith("k_shade<") and kk.rstrip(">").endswith("true") for kk in d):
+                continue                                    # flat scenes: k_shade<., false> is the counting pass's launch (the timed frames run k_shade<., true>)
             ent["kernels"][k] = v
         valu[sc] = ent
 json.dump(traffic, open(traffic_path, "w"), indent=1)
