@@ -2673,7 +2673,6 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         for (uint32_t i = threadIdx.x; i < n_lds * 4u; i += blockDim.x) s_top[i] = src[i];
         __syncthreads();
     }
-    const DNode root = nodes[0];
     const uint32_t vst = static_cast<uint32_t>(L.vsteps > 0 ? L.vsteps : 1);
     const bool blocks = sample_blocks(L);
     const float fi_last = static_cast<float>(L.usteps - 1) + 0.5f, fj_last = static_cast<float>(L.vsteps - 1) + 0.5f;
@@ -2804,9 +2803,13 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
             const unsigned long long om = __ballot(valid && occ);
             if (lane == 0 && om != 0ull) atomicAnd(&vis[vis_index], ~om);
         } else {
-            const bool sroot = valid && box_hit_verified(root.bmin, sx, sy, sz, ddx, ddy, ddz, srx, sry, srz);
+            // (the root record comes from the LDS copy of the top of the tree at each use: held in 16 scalar registers for the kernel's lifetime it was
+            //  spilled and restored around every unit -- dodge 1.079 -> 1.052 ms, cfg4 26.8 -> 26.2 ms.  Parking the shard map and the lane constants in
+            //  LDS as well cut the spilled VGPRs from 14 to 10 and LOST 1.5 %: the unit prologue waits for every extra LDS read)
+            const DNode rootl = sl.nodes[0];
+            const bool sroot = valid && box_hit_verified(rootl.bmin, sx, sy, sz, ddx, ddy, ddz, srx, sry, srz);
             const ShaftTasks TQ{Q.tasks_out + tsh * tcap, &ctl->n_task_sh[level][tsh * 16u], tcap, tasks_on ? Q.budget : 0u, Q.target ? Q.target : Q.budget, unit};
-            shaft_walk<TASKS>(nodes, tris, chunks, stk, sl, lane, root, sroot, R, srx, sry, srz, SC, TQ, occ);
+            shaft_walk<TASKS>(nodes, tris, chunks, stk, sl, lane, rootl, sroot, R, srx, sry, srz, SC, TQ, occ);
             const unsigned long long vm = __ballot(valid && !occ);
             if (lane == 0) vis[vis_index] = vm;
         }
