@@ -112,7 +112,8 @@ def work_counters(pkg, hs, W, H, G, D):
     # Control::prof[RT_WORK_SHADOW + k]: step counters of the shadow kernels (k_beam, k_shadow, k_shadow_shaft and their leaf-task launches)
     names = {0: "tri_steps_lanes_rays", 2: "tri_steps_lanes_triangles", 4: "box_steps_stack_walk", 12: "chunk_tests_stack_walk", 13: "units",
              88: "shaft_groups", 90: "nodes_tested_per_ray", 91: "nodes_hit", 92: "leaf_chunk_batches", 94: "chunks_tested_per_ray", 95: "chunks_with_work",
-             70: "tri_shaft_tests", 71: "tri_shaft_survivors", 72: "tri_shaft_rays", 73: "tri_shaft_empty_chunks", 74: "node_test_live_rays", 75: "node_hit_rays", 76: "beams_tested", 77: "beams_unblocked", 78: "beam_hits_checked_per_leaf_list", 79: "beam_hits_that_reach_a_bad_leaf", 80: "beam_steps_of_unblocked", 81: "beams_over_budget"}
+             70: "tri_shaft_tests", 71: "tri_shaft_survivors", 72: "tri_shaft_rays", 73: "tri_shaft_empty_chunks", 74: "node_test_live_rays", 75: "node_hit_rays", 76: "beams_tested", 77: "beams_unblocked", 78: "beam_hits_checked_per_leaf_list", 79: "beam_hits_that_reach_a_bad_leaf", 80: "beam_steps_of_unblocked", 81: "beams_over_budget",
+             82: "beam_group_steps", 83: "beam_children_in_shaft", 84: "beam_leaf_visits", 85: "beam_chunk_batches", 86: "beam_chunks_tested_by_triangle"}
     # Control::prof[k]: step counters of the trace kernels (k_trace / k_stage and the leaf-task launches of the two traversal stages).  They share
     # the leaf code (leaf_visit) with the shadow kernels but none of the shaft / beam steps, so the region has names of its own.
     trace_names = {0: "tri_steps_lanes_rays", 2: "tri_steps_lanes_triangles", 4: "box_steps_stack_walk", 6: "leaves_lanes_rays", 7: "leaves_lanes_triangles",

@@ -26,6 +26,8 @@ void launch_shadow_shaft_cont(int grid, hipStream_t st, const DScene &S, const D
                               Control *ctl, unsigned long long *vis, const ContTask *tasks_in, uint32_t cap, const uint32_t *sidx);
 void launch_beam(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, uint32_t item_cap, const ShadeItem *items, Control *ctl,
                  unsigned long long *vis, uint32_t *sidx);
+void launch_pair_beam(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, uint32_t item_cap, const ShadeItem *items, Control *ctl,
+                      unsigned long long *vis, uint32_t *sidx);
 void launch_shadow_cont(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, uint32_t item_cap, const ShadeItem *items,
                         Control *ctl, unsigned long long *vis, const ContTask *tasks_in, ContTask *tasks_out, uint32_t q_in, uint32_t q_out,
                         uint32_t cap, uint32_t budget, const uint32_t *sidx);
@@ -85,6 +87,8 @@ struct rt_ctx {
     uint32_t group_budget = 4u;                 // groups a trace unit pops before it hands the rest of its stack to the task launch (RT_GROUP_BUDGET, 0 = never)
     uint32_t shadow_budget = 3000u;
     bool beam_trees = false;
+    uint32_t item_beam = 1;               // tree scenes, lights of more than 64 samples: the per-hit beam test (k_pair_beam) in front of k_shadow_shaft (RT_ITEM_BEAM=0: off, 2: also for one pass)
+    int item_beam_blocks = 6;             // its workgroups per CU (6 waves per SIMD)
     bool deep = true;                     // flat scenes: levels 2 .. max_depth in ONE launch (k_deep); RT_NO_DEEP=1 keeps the four launches per level
     int shaft_min_samples = 33;           // tree scenes: sample counts from which a (hit, light) pair gets a wave of its own (k_shadow_shaft)
     uint32_t shaft_budget = 0u;           // the shaft walk culls per triangle: its leaves are cheap enough to stay inline (dodge 1080p: 1.31 -> 1.22 ms without tasks)
@@ -159,6 +163,8 @@ extern "C" rt_status rt_create(rt_ctx **out, int device) {
     if (const char *sb = std::getenv("RT_SHAFT_BUDGET")) c->shaft_budget = c->shaft_budget_deep = static_cast<uint32_t>(std::atoi(sb));
     if (const char *sm = std::getenv("RT_SHAFT_MIN_SAMPLES")) c->shaft_min_samples = std::atoi(sm);
     if (const char *bt = std::getenv("RT_BEAM_TREES")) c->beam_trees = std::atoi(bt) != 0;
+    if (const char *ib = std::getenv("RT_ITEM_BEAM")) c->item_beam = static_cast<uint32_t>(std::max(0, std::atoi(ib)));
+    if (const char *ib = std::getenv("RT_ITEM_BEAM_BLOCKS")) c->item_beam_blocks = std::max(1, std::atoi(ib));
     if (std::getenv("RT_NO_DEEP")) c->deep = false;
     if (const char *sg = std::getenv("RT_STAGED_TRACE")) c->staged_trace = std::atoi(sg) != 0;
     if (const char *sm = std::getenv("RT_STAGE_MULT")) { const int v = std::atoi(sm); if (v >= 1 && v <= 8) c->stage_mult = v; }
@@ -739,11 +745,15 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
         // of their hits can reach a leaf with one of the model's degenerate triangles -- and the shadow units drop from 213k to 33k, but a beam
         // walks ~370 steps alone in its wave (k_beam 0.30 ms) and the units that remain are the expensive ones (penumbra, cluttered parts:
         // 0.60 ms of the former 0.77): 0.90 ms against 0.77.  cfg4: 9 % unblocked; the launch's own brake stops testing after 4k of 18k tiles.)
-        const bool beam = !count && c->S.beam != 0 && (c->flat || c->beam_trees);
-        const uint32_t *sidx = beam ? c->d_sidx : nullptr;
-        if (beam) ++nl, launch_beam(c->cus * 4, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_sidx);
-        // tree scenes with one (hit, light) pair per wave: the shaft walk (rt_kernels.hip, k_shadow_shaft)
+        // tree scenes with one (hit, light) pair per wave: the shaft walk (rt_kernels.hip, k_shadow_shaft), behind the per-hit beam test (k_beam_items)
         const bool shaft = !c->flat && !count && c->S.shaft != 0 && L.n_samples >= c->shaft_min_samples;
+        // (one pass per pair -- 64 samples or fewer: a beam costs about 1.7 units and replaces one; dodge 1080p/64: 1.05 -> 1.50 ms.  Four passes, cfg4:
+        //  nine pairs in ten are decided by their beam, k_shadow_shaft 22.6 -> 11.7 ms behind 6.5 ms of beams)
+        const bool item_beam = shaft && c->S.beam != 0 && !c->beam_trees && (c->item_beam >= 2u || (c->item_beam == 1u && P > 1));
+        const bool beam = !count && c->S.beam != 0 && (c->flat || c->beam_trees);
+        const uint32_t *sidx = (beam || item_beam) ? c->d_sidx : nullptr;
+        if (beam) ++nl, launch_beam(c->cus * 4, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_sidx);
+        if (item_beam) ++nl, launch_pair_beam(c->cus * c->item_beam_blocks, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_sidx);
         const uint32_t shaft_b = level == 0 ? c->shaft_budget : c->shaft_budget_deep;
         if (shaft)
             ++nl, launch_shadow_shaft(c->cus * c->occ_shaft, st, c->S, L, level, 3 * level + 1, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis,

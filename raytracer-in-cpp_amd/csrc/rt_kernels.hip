@@ -2642,6 +2642,9 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(F
 #ifndef RT_SHAFT_WPE
 #define RT_SHAFT_WPE 6
 #endif
+#ifndef RT_UNIT_STRIDE
+#define RT_UNIT_STRIDE 0          // RT_UNIT_HIST build: every 2^RT_UNIT_STRIDE-th unit of the level-0 shaft launch is recorded
+#endif
 template <bool CONT, bool TASKS>
 __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(RT_SHAFT_WPE, 8)))
 void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris, const ChunkBound *__restrict__ chunks,
@@ -2817,11 +2820,13 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         pclk.to(7);
 #endif
 #ifdef RT_UNIT_HIST
-        if (!CONT && !TASKS && level == 0 && S.dbg != nullptr && work < 65536u) {
-            // unit record (kernel block 4 of the debug buffer): cycles / 16, then the eight step counters of g_uh -- 9 words of a 16-word slot
+        if (!CONT && !TASKS && level == 0 && S.dbg != nullptr && (work & ((1u << RT_UNIT_STRIDE) - 1u)) == 0u && (work >> RT_UNIT_STRIDE) < 65536u) {
+            // unit record (kernel block 4 of the debug buffer): cycles / 16, the eight step counters of g_uh, occluded and valid rays -- 11 words of a 16-word slot
             const unsigned long long dtu = (static_cast<unsigned long long>(clock64()) - uh_t0) >> 4;
+            const uint32_t n_occ = static_cast<uint32_t>(__popcll(__ballot(valid && occ))), n_val = static_cast<uint32_t>(__popcll(__ballot(valid)));
             __builtin_amdgcn_wave_barrier();
-            if (lane < 9) S.dbg[RT_UNIT_DBG_WORDS + static_cast<size_t>(work) * 16u + static_cast<uint32_t>(lane)] = lane == 0 ? static_cast<uint32_t>(dtu) : g_uh[wave * 8 + lane - 1];
+            if (lane < 11) S.dbg[RT_UNIT_DBG_WORDS + static_cast<size_t>(work >> RT_UNIT_STRIDE) * 16u + static_cast<uint32_t>(lane)] =
+                lane == 0 ? static_cast<uint32_t>(dtu) : (lane == 9 ? n_occ : (lane == 10 ? n_val : g_uh[wave * 8 + lane - 1]));
         }
 #endif
 #ifdef RT_PROFILE
@@ -2961,6 +2966,9 @@ __device__ __forceinline__ void item_plane_test(const ItemPlane &p, const float 
 #ifndef RT_BEAM_BUDGET
 #define RT_BEAM_BUDGET 1024               // group steps + chunk bound batches + chunks tested triangle by triangle, per beam
 #endif
+#ifndef RT_PAIR_WPE
+#define RT_PAIR_WPE 6
+#endif
 #define RT_BEAM_REC 13                 // float4 per wave: shaft_tri_store's 11 (planes, near box, (h_c, m0), S lo, S hi) + H lo, H hi
 
 // lane = triangle: can ANY segment of the beam hit this triangle with a counted t?  (planes and near box from the relaxed record)
@@ -2992,6 +3000,7 @@ __device__ __forceinline__ bool beam_leaf(const uint32_t first, const uint32_t c
         if (nv != 0ull && !per_item) return true;
         cm &= ~nv;
         budget -= 1 + static_cast<int>(__popcll(cm));
+        RT_PROF_ADD(lane, 85, 1); RT_PROF_ADD(lane, 86, __popcll(cm)); if (cb0 == 0u) RT_PROF_ADD(lane, 84, 1);
         if (budget < 0) return true;                                       // too much work for one wave: let the shadow units decide
         while (cm != 0ull) {
             const int j = static_cast<int>(__builtin_ctzll(cm));
@@ -3006,27 +3015,124 @@ __device__ __forceinline__ bool beam_leaf(const uint32_t first, const uint32_t c
     return false;
 }
 
-// (Measured and rejected: running this inside the flat k_trace on the tile's own hits -- no k_beam launch, no second pass over the items.
-// The kernel grows from ~90 to 145 VGPRs, its primary launch from 57 to 84 us, and the frame stays at 0.40 ms.)
-// One tile of lit hits (lane = hit: `have`, its item storage index, hit point and light mode) through the beam test: writes the visibility
-// words of the hits nothing can block, appends the others to the survivor list, accounts the sample rays of the former.
+// no sample segment of light (px, py, pz) to the hit h has a zero direction component (0/0 = NaN makes the reference's min/max chain accept any box)
+__device__ __forceinline__ bool beam_dirs_ok(const DLights &L, const LightGrid &lg, const uint32_t N, const float px, const float py, const float pz,
+                                             const float hx, const float hy, const float hz) {
+    bool dirs_ok = fabsf(hx) + fabsf(hy) + fabsf(hz) < 1e30f;
+    if (L.mode == RT_LIGHT_SPHERE) {
+        for (uint32_t k = 0u; k < N; ++k) {
+            float sx, sy, sz;
+            sphere_sample(L, k, px, py, pz, sx, sy, sz);
+            dirs_ok = dirs_ok && (hx - sx != 0.0f) && (hy - sy != 0.0f) && (hz - sz != 0.0f);
+        }
+    } else {
+        float sx, sy, sz;
+        for (int i = 0; i < L.usteps; ++i) { grid_sample(lg, static_cast<float>(i) + 0.5f, 0.5f, sx, sy, sz); dirs_ok = dirs_ok && (hx - sx != 0.0f); }
+        for (int j = 0; j < L.vsteps; ++j) { grid_sample(lg, 0.5f, static_cast<float>(j) + 0.5f, sx, sy, sz); dirs_ok = dirs_ok && (hy - sy != 0.0f); }
+        dirs_ok = dirs_ok && (hz - sz != 0.0f);
+    }
+    return dirs_ok;
+}
+
+// the same for a wave-uniform hit, the samples spread over the lanes
+__device__ __forceinline__ bool beam_dirs_ok_wave(const DLights &L, const LightGrid &lg, const uint32_t N, const float px, const float py, const float pz,
+                                                  const float hx, const float hy, const float hz, const int lane) {
+    bool bad = !(fabsf(hx) + fabsf(hy) + fabsf(hz) < 1e30f);
+    if (L.mode == RT_LIGHT_SPHERE) {
+        for (uint32_t k = static_cast<uint32_t>(lane); k < N; k += 64u) {
+            float sx, sy, sz;
+            sphere_sample(L, k, px, py, pz, sx, sy, sz);
+            bad = bad || !((hx - sx != 0.0f) && (hy - sy != 0.0f) && (hz - sz != 0.0f));
+        }
+    } else {
+        float sx, sy, sz;
+        for (int i = lane; i < L.usteps; i += 64) { grid_sample(lg, static_cast<float>(i) + 0.5f, 0.5f, sx, sy, sz); bad = bad || !(hx - sx != 0.0f); }
+        for (int j = lane; j < L.vsteps; j += 64) { grid_sample(lg, 0.5f, static_cast<float>(j) + 0.5f, sx, sy, sz); bad = bad || !(hy - sy != 0.0f); }
+        grid_sample(lg, 0.5f, 0.5f, sx, sy, sz);
+        bad = bad || !(hz - sz != 0.0f);
+    }
+    return __ballot(bad) == 0ull;
+}
+
 struct BeamCtx {
     const DNode *nodes; const TriRec *tris; const ChunkBound *chunks;
     uint32_t *stack; float4 *rec; float4 *shaft;           // per-wave LDS
     uint32_t *yield; bool brake, per_item, blocks;
     uint32_t N, P, item_cap; int lslots, level;
     float fi_last, fj_last;
+    const DNode *lds_nodes; uint32_t n_lds;                // the top of the tree in LDS (k_pair_beam), or (nullptr, 0)
 };
+// The walk of one beam: groups of children by content box (and, for a beam with ONE hit, by own box against the shaft and the far cone behind the
+// hit: a child outside both is entered by no sample ray -- shaft_walk's rule, with its condition `far_ok`: no ray with a zero / non-finite
+// direction component), leaves chunk by chunk, triangle by triangle.  true = something may block a segment of the beam (or the budget ran out).
+__device__ __forceinline__ bool beam_walk(const BeamCtx &B, const DScene &S, const DNode &root, const int lane, const ShaftCtl &SC, const bool far_ok, int &budget) {
+    const DNode *__restrict__ nodes = B.nodes; const TriRec *__restrict__ tris = B.tris; const ChunkBound *__restrict__ chunks = B.chunks;
+    uint32_t *const stack = B.stack; float4 *const rec = B.rec; float4 *const shaft = B.shaft;
+    const bool per_item = B.per_item;
+    const int tk = lane & 7, tc = lane >> 3;
+    bool blocked = false;
+    int sp = 0;
+    if (root.count_flags & RT_NODE_LEAF) {
+        blocked = (root.count_flags & 0x7fffffffu) != 0u &&
+                  beam_leaf(uniform_u32(root.first), uniform_u32(root.count_flags) & 0x7fffffffu, uniform_u32(root.pad[0]), tris, chunks, lane, shaft, rec, SC, per_item, budget);
+    } else if ((root.count_flags & 0xfu) != 0u) {
+        if (lane == 0) stack[0] = root.first | ((root.count_flags & 0xfu) << 28);
+        sp = 1;
+    }
+    while (sp > 0 && !blocked) {
+        --sp;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t ent = uniform_u32(stack[sp]);
+        const uint32_t base = ent & 0x0fffffffu, gcnt = ent >> 28;
+        const uint32_t ci = base + (static_cast<uint32_t>(tc) < gcnt ? static_cast<uint32_t>(tc) : 0u);
+        DNode ch;
+        if (base + gcnt <= B.n_lds) ch = B.lds_nodes[ci];
+        else ch = nodes[ci];
+        const ShaftLanes SLg = shaft_lanes_load(shaft, tk, SC);
+        bool c_near, c_far;
+        shaft_lane_test(SLg, tk, ch.clo[0] - SC.pad, ch.clo[1] - SC.pad, ch.clo[2] - SC.pad, ch.chi[0] + SC.pad, ch.chi[1] + SC.pad, ch.chi[2] + SC.pad, c_near, c_far);
+        // (per_item: the content box bounds the cullable chunks below; the others are tested per hit afterwards)
+        const unsigned long long b_c = __ballot(c_near && (ch.pad[1] == 0u || per_item));
+        bool culled = ballot_byte_any(b_c, lane);
+        if (far_ok) {
+            bool n_near, n_far;
+            shaft_lane_test(SLg, tk, ch.bmin[0] - SC.pad, ch.bmin[1] - SC.pad, ch.bmin[2] - SC.pad, ch.bmax[0] + SC.pad, ch.bmax[1] + SC.pad, ch.bmax[2] + SC.pad, n_near, n_far);
+            const unsigned long long b_nn = __ballot(n_near), b_nf = __ballot(n_far);
+            culled = culled || (ballot_byte_any(b_nn, lane) && ballot_byte_any(b_nf, lane));
+        }
+        unsigned long long surv = __ballot(static_cast<uint32_t>(lane) < gcnt && !culled);
+        if (--budget < 0) blocked = true;
+        RT_PROF_ADD(lane, 82, 1); RT_PROF_ADD(lane, 83, __popcll(surv));
+        while (surv != 0ull && !blocked) {
+            const int j = static_cast<int>(__builtin_ctzll(surv));
+            surv &= surv - 1ull;
+            const uint32_t cf = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.count_flags), 8 * j));
+            const uint32_t ff = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.first), 8 * j));
+            if (cf & RT_NODE_LEAF) {
+                const uint32_t lc = cf & 0x7fffffffu;
+                if (lc != 0u) blocked = beam_leaf(ff, lc, static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.pad[0]), 8 * j)), tris, chunks, lane, shaft, rec, SC, per_item, budget);
+            } else if ((cf & 0xfu) != 0u) {
+                if (lane == 0) stack[sp] = ff | ((cf & 0xfu) << 28);
+                ++sp;
+            }
+        }
+    }
+    return blocked;
+}
+
+// (Measured and rejected: running this inside the flat k_trace on the tile's own hits -- no k_beam launch, no second pass over the items.
+// The kernel grows from ~90 to 145 VGPRs, its primary launch from 57 to 84 us, and the frame stays at 0.40 ms.)
+// One tile of lit hits (lane = hit: `have`, its item storage index, hit point and light mode) through the beam test: writes the visibility
+// words of the hits nothing can block, appends the others to the survivor list, accounts the sample rays of the former.
 __device__ __forceinline__ void beam_tile(const BeamCtx &B, const DScene &S, const DLights &L, const DNode &root, Control *__restrict__ ctl,
                                           unsigned long long *__restrict__ vis, uint32_t *__restrict__ sidx, const int lane, const uint32_t tile,
                                           const bool have, const uint32_t idx, const float hx, const float hy, const float hz, const uint32_t lmode, uint32_t &c_rays) {
-    const DNode *__restrict__ nodes = B.nodes; const TriRec *__restrict__ tris = B.tris; const ChunkBound *__restrict__ chunks = B.chunks;
-    uint32_t *const stack = B.stack; float4 *const rec = B.rec; float4 *const shaft = B.shaft; uint32_t *const yield = B.yield;
+    float4 *const rec = B.rec; float4 *const shaft = B.shaft; uint32_t *const yield = B.yield;
     const bool brake = B.brake, per_item = B.per_item, blocks = B.blocks;
     const uint32_t N = B.N, P = B.P, item_cap = B.item_cap;
     const int lslots = B.lslots, level = B.level;
     const float fi_last = B.fi_last, fj_last = B.fj_last;
-    const int tk = lane & 7, tc = lane >> 3;
+    const int tk = lane & 7;
     const bool scene = have && lmode == 0u;              // sees the scene lights (a mirror bounce carries a light list of its own)
     bool survive = have && !scene;
     const unsigned long long sm0 = __ballot(scene);
@@ -3070,43 +3176,8 @@ __device__ __forceinline__ void beam_tile(const BeamCtx &B, const DScene &S, con
                 rec[8] = make_float4(cx, cy, cz, m0); rec[11] = make_float4(lx, ly, lz, 0.f); rec[12] = make_float4(ux, uy, uz, 0.f);
             }
             __builtin_amdgcn_wave_barrier();
-            // ---- the walk: groups of children by content box, leaves chunk by chunk, triangle by triangle
-            bool blocked = false;
-            int sp = 0, budget = S.beam_budget;
-            if (root.count_flags & RT_NODE_LEAF) {
-                blocked = (root.count_flags & 0x7fffffffu) != 0u &&
-                          beam_leaf(uniform_u32(root.first), uniform_u32(root.count_flags) & 0x7fffffffu, uniform_u32(root.pad[0]), tris, chunks, lane, shaft, rec, SC, per_item, budget);
-            } else if ((root.count_flags & 0xfu) != 0u) {
-                if (lane == 0) stack[0] = root.first | ((root.count_flags & 0xfu) << 28);
-                sp = 1;
-            }
-            while (sp > 0 && !blocked) {
-                --sp;
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t ent = uniform_u32(stack[sp]);
-                const uint32_t base = ent & 0x0fffffffu, gcnt = ent >> 28;
-                const DNode ch = nodes[base + (static_cast<uint32_t>(tc) < gcnt ? static_cast<uint32_t>(tc) : 0u)];
-                const ShaftLanes SLg = shaft_lanes_load(shaft, tk, SC);
-                bool c_near, c_far;
-                shaft_lane_test(SLg, tk, ch.clo[0] - SC.pad, ch.clo[1] - SC.pad, ch.clo[2] - SC.pad, ch.chi[0] + SC.pad, ch.chi[1] + SC.pad, ch.chi[2] + SC.pad, c_near, c_far);
-                // (per_item: the content box bounds the cullable chunks below; the others are tested per hit afterwards)
-                const unsigned long long b_c = __ballot(c_near && (ch.pad[1] == 0u || per_item));
-                unsigned long long surv = __ballot(static_cast<uint32_t>(lane) < gcnt && !ballot_byte_any(b_c, lane));
-                if (--budget < 0) blocked = true;
-                while (surv != 0ull && !blocked) {
-                    const int j = static_cast<int>(__builtin_ctzll(surv));
-                    surv &= surv - 1ull;
-                    const uint32_t cf = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.count_flags), 8 * j));
-                    const uint32_t ff = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.first), 8 * j));
-                    if (cf & RT_NODE_LEAF) {
-                        const uint32_t lc = cf & 0x7fffffffu;
-                        if (lc != 0u) blocked = beam_leaf(ff, lc, static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ch.pad[0]), 8 * j)), tris, chunks, lane, shaft, rec, SC, per_item, budget);
-                    } else if ((cf & 0xfu) != 0u) {
-                        if (lane == 0) stack[sp] = ff | ((cf & 0xfu) << 28);
-                        ++sp;
-                    }
-                }
-            }
+            int budget = S.beam_budget;
+            const bool blocked = beam_walk(B, S, root, lane, SC, false, budget);
             RT_PROF_ADD(lane, 76, 1); RT_PROF_ADD(lane, 77, blocked ? 0 : 1); RT_PROF_ADD(lane, 80, blocked ? 0 : S.beam_budget - budget); RT_PROF_ADD(lane, 81, budget < 0 ? 1 : 0);
             if (brake && lane == 0) { atomicAdd(&yield[0], 1u); if (!blocked) atomicAdd(&yield[1], 1u); }
             // the leaves with a chunk that may never be culled (degenerate triangles whose computed barycentrics are noise): can a ray to
@@ -3116,19 +3187,7 @@ __device__ __forceinline__ void beam_tile(const BeamCtx &B, const DScene &S, con
             // direction component: 0/0 = NaN makes the reference's min/max chain accept -- such hits stay with the shadow units.)
             bool reach = false;
             if (!blocked && per_item && S.n_bad_leaves != 0u) {
-                bool dirs_ok = fabsf(hx) + fabsf(hy) + fabsf(hz) < 1e30f;
-                if (L.mode == RT_LIGHT_SPHERE) {
-                    for (uint32_t k = 0u; k < N; ++k) {
-                        float sx, sy, sz;
-                        sphere_sample(L, k, px, py, pz, sx, sy, sz);
-                        dirs_ok = dirs_ok && (hx - sx != 0.0f) && (hy - sy != 0.0f) && (hz - sz != 0.0f);
-                    }
-                } else {
-                    float sx, sy, sz;
-                    for (int i = 0; i < L.usteps; ++i) { grid_sample(lg, static_cast<float>(i) + 0.5f, 0.5f, sx, sy, sz); dirs_ok = dirs_ok && (hx - sx != 0.0f); }
-                    for (int j = 0; j < L.vsteps; ++j) { grid_sample(lg, 0.5f, static_cast<float>(j) + 0.5f, sx, sy, sz); dirs_ok = dirs_ok && (hy - sy != 0.0f); }
-                    dirs_ok = dirs_ok && (hz - sz != 0.0f);
-                }
+                const bool dirs_ok = beam_dirs_ok(L, lg, N, px, py, pz, hx, hy, hz);
                 const float big = fmaxf(fmaxf(fabsf(slx), fabsf(shx)), fmaxf(fabsf(sly), fabsf(shy))) + fmaxf(fabsf(slz), fabsf(shz));
                 const float scale = S.extent + big + (fabsf(hx) + fabsf(hy) + fabsf(hz));
                 const float pad = 4e-4f * ((fmaxf(fabsf(slx), fabsf(shx)) + fmaxf(fabsf(sly), fabsf(shy)) + fmaxf(fabsf(slz), fabsf(shz))) + S.extent) * 1.001f;
@@ -3204,7 +3263,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_beam(const DNode *__restrict_
     // that report to it pass their remaining tiles on untested.  The results do not depend on it -- an untested tile simply goes to the shadow kernels.
     uint32_t *const yield = ctl->beam_yield[level] + (blockIdx.x & (RT_LIST_SHARDS - 1u)) * 16u;      // this workgroup's shard (one returning or
                                                                                                       // non-returning atomic word takes ~88 updates per microsecond)
-    const BeamCtx B{nodes, tris, chunks, stack, rec, shaft, yield, brake, per_item, blocks, N, P, item_cap, lslots, level, fi_last, fj_last};
+    const BeamCtx B{nodes, tris, chunks, stack, rec, shaft, yield, brake, per_item, blocks, N, P, item_cap, lslots, level, fi_last, fj_last, nullptr, 0u};
     for (uint32_t tile = wave_id; tile < ntiles; tile += wave_count) {
         uint32_t sh, tj, n_sh;
         shard_find(imap, tile, sh, tj, n_sh);
@@ -3215,6 +3274,164 @@ __global__ __launch_bounds__(RT_WAVES * 64) void k_beam(const DNode *__restrict_
         beam_tile(B, S, L, root, ctl, vis, sidx, lane, tile, have, idx, hx, hy, hz, it.lmode, c_rays);
     }
     c_rays = wave_sum(c_rays);
+    if (lane == 0 && c_rays) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_SAMPLE], static_cast<unsigned long long>(c_rays));
+}
+
+// The beam test at the granularity of ONE lit hit -- tree scenes with more than 64 samples per light, in front of k_shadow_shaft.
+// A (hit, light) pair is 2 to 16 shadow units there (one per 64-sample pass), each of which builds its own shaft and walks the top of the tree
+// on its own; where nothing at all lies between the hit and the light -- nine units in ten under the 16 x 16 light of the 4K height field, and
+// they were half of that kernel's time -- ONE walk with the shaft of the whole light decides all passes at once: the visibility words are
+// written here and the pair never becomes a unit.  The apex of the shaft is the hit itself, so (unlike a 64-hit tile, whose apex is a box)
+//   * the shaft is the exact hull of the hit and the light's samples plus the rounding margins: the surface around the hit does not block it
+//     (the hit's own face and its near-coplanar neighbours are ruled out by plane_rules_out_box's t > 0.981 rule);
+//   * the far cone behind the hit is known, so a child whose OWN box lies outside the shaft and outside the far cone is skipped exactly as
+//     shaft_walk skips it -- in the reference's over-inclusive tree (clasifyFace tests normalised vectors) the content boxes alone cull
+//     almost nothing: 7.5 of 8 children survived per group, 360 steps per beam; with the own-box rule 2.7 of 8 and 11 steps (dodge).
+// One wave = one hit at a time, taken from the item list as k_shadow_shaft takes its units (wave-uniform: the item is a scalar load, the hit
+// lives in SGPRs): lane = (child, test) in the walk, lane = chunk / triangle in the leaves, lane = leaf in the check against the leaves that
+// hold a chunk which may never be culled, lane = pass when the visibility words are written.  A beam is a chain of dependent loads like a
+// shadow unit (~2 groups, ~4 leaves with their chunk bounds and triangles), so what counts is how many run at once: everything per hit is
+// scalar, the kernel fits the register budget of 6 waves per SIMD.  Hits that may be blocked go to the survivor list of their OWN list
+// shard (its capacity holds every item of the shard), 16 at a time through a per-wave LDS buffer.
+// The brake is k_beam's: a shard's waves stop testing once it has seen 256 beams with fewer than a quarter unblocked (counters updated
+// every 16 beams per wave).
+#define RT_PAIR_BUF 16
+__global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(RT_PAIR_WPE, 8)))
+void k_pair_beam(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris, const ChunkBound *__restrict__ chunks,
+                 const DScene S, const DLights L, const int level, const int lslots, const uint32_t item_cap,
+                 const ShadeItem *__restrict__ items, Control *__restrict__ ctl, unsigned long long *__restrict__ vis,
+                 uint32_t *__restrict__ sidx) {
+    __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
+    __shared__ float4 s_rec[RT_WAVES * RT_BEAM_REC];
+    __shared__ float4 s_shaft[RT_WAVES * 16];
+    __shared__ uint4 s_top[RT_LDS_NODES * 4];           // the top of the octree, as in k_shadow_shaft
+    __shared__ float s_bad[32 * 6];                     // boxes of the leaves with a chunk that may never be culled (at most 32: rt_capi.cpp)
+    __shared__ uint32_t s_buf[RT_WAVES * RT_PAIR_BUF];  // survivors waiting for their list reservation
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *const stack = s_node + wave * RT_STACK;
+    float4 *const rec = s_rec + wave * RT_BEAM_REC;
+    float4 *const shaft = s_shaft + wave * 16;
+    uint32_t *const buf = s_buf + wave * RT_PAIR_BUF;
+    const ShardMap imap = shard_map(ctl->n_items[level], lane, item_cap, 1u, 1u);
+    const uint32_t n_items = imap.total;
+    if (n_items == 0u) return;
+    const uint32_t n_lds = S.n_nodes < RT_LDS_NODES ? S.n_nodes : RT_LDS_NODES;
+    const bool per_item = S.n_bad_leaves != 0xffffffffu;
+    const uint32_t n_bad = per_item ? S.n_bad_leaves : 0u;
+    {
+        const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(nodes);
+        for (uint32_t i = threadIdx.x; i < n_lds * 4u; i += blockDim.x) s_top[i] = src[i];
+        if (threadIdx.x < n_bad * 6u) s_bad[threadIdx.x] = S.bad_leaves[threadIdx.x];
+        __syncthreads();
+    }
+    const uint32_t N = static_cast<uint32_t>(L.n_samples);
+    const uint32_t P = (N + 63u) / 64u;
+    const bool blocks = sample_blocks(L);
+    const float fi_last = static_cast<float>(L.usteps - 1) + 0.5f, fj_last = static_cast<float>(L.vsteps - 1) + 0.5f;
+    uint32_t c_rays = 0;
+    const uint32_t wave_id = uniform_u32(blockIdx.x * RT_WAVES + static_cast<uint32_t>(wave)), wave_count = gridDim.x * RT_WAVES;
+    uint32_t *const yield = ctl->beam_yield[level] + (blockIdx.x & (RT_LIST_SHARDS - 1u)) * 16u;
+    const BeamCtx B{nodes, tris, chunks, stack, rec, shaft, yield, false, per_item, blocks, N, P, item_cap, lslots, level, fi_last, fj_last,
+                    reinterpret_cast<const DNode *>(s_top), n_lds};
+    const int tk = lane & 7;
+    uint32_t n_buf = 0u, buf_shard = 0u;            // survivors in the buffer, all of list shard buf_shard
+    uint32_t n_tested = 0u, n_unblocked = 0u, since = 0u;
+    bool give_up = false;
+    auto flush = [&]() {
+        if (n_buf == 0u) return;
+        uint32_t base = 0u;
+        if (lane == 0) base = atomicAdd(&ctl->n_sitems[level][buf_shard * 16u], n_buf);
+        base = uniform_u32(base);
+        __builtin_amdgcn_wave_barrier();
+        if (static_cast<uint32_t>(lane) < n_buf) {
+            if (base + n_buf <= item_cap) sidx[buf_shard * item_cap + base + static_cast<uint32_t>(lane)] = buf[lane];
+            else if (lane == 0) atomicOr(&ctl->overflow, 1u);           // (never: the shard's survivors are a subset of its items)
+        }
+        __builtin_amdgcn_wave_barrier();
+        n_buf = 0u;
+    };
+    for (uint32_t w = wave_id; w < n_items; w += wave_count) {
+        uint32_t sh, li, n_sh;
+        shard_find(imap, w, sh, li, n_sh);
+        const uint32_t idx = uniform_u32(sh * item_cap + li);               // item storage index (also keys vis)
+        const ShadeItem it = items[idx];                                    // wave-uniform: a scalar load
+        const float ax = it.ox + it.t * it.dx, ay = it.oy + it.t * it.dy, az = it.oz + it.t * it.dz;      // the hit, as the shadow kernels form it
+        bool survive = it.lmode != 0u || give_up;          // (a mirror bounce carries a light list of its own: straight to the shadow units)
+        for (int l = 0; l < L.n_lights && !survive; ++l) {
+            float x0, y0, z0, x1, y1, z1;
+            const float px = L.pos[l][0], py = L.pos[l][1], pz = L.pos[l][2];
+            const LightGrid lg = light_grid(L, px, py, pz);
+            grid_sample(lg, 0.5f, 0.5f, x0, y0, z0);             // the samples are monotone in each grid index: two corners give the exact box
+            grid_sample(lg, fi_last, fj_last, x1, y1, z1);
+            if (L.mode == RT_LIGHT_SPHERE) sphere_box(L, px, py, pz, x0, y0, z0, x1, y1, z1);
+            const float slx = fminf(x0, x1), sly = fminf(y0, y1), slz = fminf(z0, z1), shx = fmaxf(x0, x1), shy = fmaxf(y0, y1), shz = fmaxf(z0, z1);
+            const float e = 1e-7f * S.extent;
+            ShaftLanes SL = make_shaft_lanes(lane, ax, ay, az, slx, sly, slz, shx, shy, shz, S.extent);
+            shaft_inflate(SL, tk, e, e, e);
+            const ShaftCtl SC{SL.pad, false};
+            __builtin_amdgcn_wave_barrier();
+            shaft_tri_store(rec, lane, SL, ax, ay, az, slx, sly, slz, shx, shy, shz);
+            shaft_lanes_store(shaft, lane, SL);
+            if (lane == 8) {
+                const float m0 = 2e-5f * (((fabsf(slx) + fabsf(shx)) + (fabsf(sly) + fabsf(shy)) + (fabsf(slz) + fabsf(shz))) +
+                                          ((fabsf(ax) + fabsf(ax)) + (fabsf(ay) + fabsf(ay)) + (fabsf(az) + fabsf(az))));
+                rec[8] = make_float4(ax, ay, az, m0); rec[11] = make_float4(ax, ay, az, 0.f); rec[12] = make_float4(ax, ay, az, 0.f);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const bool dirs_ok = beam_dirs_ok_wave(L, lg, N, px, py, pz, ax, ay, az, lane);
+            int budget = S.beam_budget;
+            const DNode root = B.lds_nodes[0];
+            bool blocked = beam_walk(B, S, root, lane, SC, dirs_ok, budget);
+            RT_PROF_ADD(lane, 76, 1); RT_PROF_ADD(lane, 77, blocked ? 0 : 1); RT_PROF_ADD(lane, 80, blocked ? 0 : S.beam_budget - budget); RT_PROF_ADD(lane, 81, budget < 0 ? 1 : 0);
+            n_tested += 1u; n_unblocked += blocked ? 0u : 1u;
+            // the leaves with a chunk that may never be culled (beam_tile has the argument): lane = leaf
+            if (!blocked && n_bad != 0u) {
+                const float big = fmaxf(fmaxf(fabsf(slx), fabsf(shx)), fmaxf(fabsf(sly), fabsf(shy))) + fmaxf(fabsf(slz), fabsf(shz));
+                const float scale = S.extent + big + (fabsf(ax) + fabsf(ay) + fabsf(az));
+                const float pad = 4e-4f * ((fmaxf(fabsf(slx), fabsf(shx)) + fmaxf(fabsf(sly), fabsf(shy)) + fmaxf(fabsf(slz), fabsf(shz))) + S.extent) * 1.001f;
+                const ItemPlane p0 = item_plane<0, false>(ax, ay, az, slx, sly, slz, shx, shy, shz, scale), p1 = item_plane<0, true>(ax, ay, az, slx, sly, slz, shx, shy, shz, scale);
+                const ItemPlane p2 = item_plane<1, false>(ax, ay, az, slx, sly, slz, shx, shy, shz, scale), p3 = item_plane<1, true>(ax, ay, az, slx, sly, slz, shx, shy, shz, scale);
+                const ItemPlane p4 = item_plane<2, false>(ax, ay, az, slx, sly, slz, shx, shy, shz, scale), p5 = item_plane<2, true>(ax, ay, az, slx, sly, slz, shx, shy, shz, scale);
+                const float nlx = fminf(slx, ax), nly = fminf(sly, ay), nlz = fminf(slz, az), nhx = fmaxf(shx, ax), nhy = fmaxf(shy, ay), nhz = fmaxf(shz, az);
+                const float flx = ax >= shx ? ax : -3e38f, fly = ay >= shy ? ay : -3e38f, flz = az >= shz ? az : -3e38f;
+                const float fhx = ax <= slx ? ax : 3e38f, fhy = ay <= sly ? ay : 3e38f, fhz = az <= slz ? az : 3e38f;
+                const float *bb = s_bad + 6u * (static_cast<uint32_t>(lane) < n_bad ? static_cast<uint32_t>(lane) : 0u);
+                const float lx_ = bb[0] - pad, ly_ = bb[1] - pad, lz_ = bb[2] - pad, hx_ = bb[3] + pad, hy_ = bb[4] + pad, hz_ = bb[5] + pad;
+                bool near_out = (lx_ > nhx) || (hx_ < nlx) || (ly_ > nhy) || (hy_ < nly) || (lz_ > nhz) || (hz_ < nlz);
+                bool far_out = (lx_ > fhx) || (hx_ < flx) || (ly_ > fhy) || (hy_ < fly) || (lz_ > fhz) || (hz_ < flz);
+                item_plane_test<0>(p0, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out); item_plane_test<0>(p1, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out);
+                item_plane_test<1>(p2, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out); item_plane_test<1>(p3, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out);
+                item_plane_test<2>(p4, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out); item_plane_test<2>(p5, lx_, ly_, lz_, hx_, hy_, hz_, near_out, far_out);
+                blocked = __ballot(static_cast<uint32_t>(lane) < n_bad && !(dirs_ok && near_out && far_out)) != 0ull;
+                RT_PROF_ADD(lane, 78, 1); RT_PROF_ADD(lane, 79, blocked ? 1 : 0);
+            }
+            if (blocked) {
+                survive = true;              // (the words of lights already written stay: the unit kernel rewrites the same values)
+            } else if (static_cast<uint32_t>(lane) < P) {
+                // nothing can block any sample segment of this hit to light l: all N samples visible (lane = pass)
+                const uint32_t left = N - static_cast<uint32_t>(lane) * 64u;
+                vis[(static_cast<unsigned long long>(idx) * static_cast<unsigned long long>(lslots) + static_cast<unsigned long long>(l)) * P + static_cast<uint32_t>(lane)] =
+                    (blocks || left >= 64u) ? ~0ull : ((1ull << left) - 1ull);
+            }
+        }
+        if (survive) {
+            if (n_buf != 0u && buf_shard != sh) flush();
+            buf_shard = sh;
+            if (lane == 0) buf[n_buf] = idx;
+            if (++n_buf == RT_PAIR_BUF) flush();
+        } else {
+            c_rays += N * static_cast<uint32_t>(L.n_lights);        // sample rays that never become a shadow unit are accounted for here (wave-uniform)
+        }
+        if (++since == 16u && !give_up) {
+            since = 0u;
+            uint32_t a = 0u, b = 0u;
+            if (lane == 0) { a = atomicAdd(&yield[0], n_tested) + n_tested; b = atomicAdd(&yield[1], n_unblocked) + n_unblocked; }
+            a = uniform_u32(a); b = uniform_u32(b);
+            n_tested = 0u; n_unblocked = 0u;
+            give_up = a >= 256u && b * 4u < a;
+        }
+    }
+    flush();
     if (lane == 0 && c_rays) atomicAdd(&ctl->stat[blockIdx.x & (RT_STAT_SHARDS - 1)][ST_RAYS_SAMPLE], static_cast<unsigned long long>(c_rays));
 }
 
@@ -3949,6 +4166,11 @@ void launch_shadow_cont(int grid, hipStream_t st, const DScene &S, const DLights
 void launch_beam(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, uint32_t item_cap, const ShadeItem *items, Control *ctl,
                  unsigned long long *vis, uint32_t *sidx) {
     hipLaunchKernelGGL(k_beam, dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S, L, level, lslots, item_cap, items, ctl, vis, sidx);
+}
+
+void launch_pair_beam(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, uint32_t item_cap, const ShadeItem *items, Control *ctl,
+                      unsigned long long *vis, uint32_t *sidx) {
+    hipLaunchKernelGGL(k_pair_beam, dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S, L, level, lslots, item_cap, items, ctl, vis, sidx);
 }
 
 void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level, int slot, int lslots,

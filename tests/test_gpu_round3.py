@@ -265,3 +265,67 @@ def test_cfg5_animation_120_frames_1080p_graph_replay(rt, oracle, scene):
     st = g.stats()
     assert st.total_rays() > 0 and len(set(shas[:4])) == 4          # the camera really moved
     g.close(); out.free(); out8.free(); osc.close(); ctx.close(); hs.close()
+
+
+# ------------------------------------------------------------------------------------------ the per-hit beam test of tree scenes (k_pair_beam)
+def _render_stats(rt, ctx, cam, L, w, h, depth):
+    p = rt.make_params(w, h, depth)
+    rgb = np.zeros((h, w, 3), np.float32)
+    hits = np.zeros((h, w), np.int32)
+    st = rt.capi.rt_stats()
+    rc = ctx.lib.rt_render(ctx.handle, C.byref(cam), C.byref(L), C.byref(p), rgb.ctypes.data_as(C.c_void_p), hits.ctypes.data_as(C.c_void_p), C.byref(st))
+    rt.capi.check(ctx.lib, ctx.handle, rc, "rt_render")
+    return rgb, hits, st
+
+
+PAIR_CASES = [("dodgeColorTest.obj", "grid", 16, 16, 1, 3),      # blocks of 8 x 8, four passes: the case it is on for by default
+              ("dodgeColorTest.obj", "grid", 10, 10, 2, 2),      # 100 samples in two strips (no blocks), two lights
+              ("dodgeColorTest.obj", "grid", 8, 8, 1, 4),        # one pass: only with RT_ITEM_BEAM=2; mirror bounces carry light lists of their own
+              ("dodgeColorTest.obj", "sphere", 100, 0, 1, 2),    # seeded sphere samples (their box comes from the offsets)
+              ("bunny.ply", "grid", 16, 8, 1, 2),                # a deep tree (361 nodes: groups beyond the LDS copy of the top)
+              ("wavy", "grid", 16, 16, 1, 2),                    # the height field of cfg4 (grazing light: many beams blocked)
+              ("mixed", "grid", 12, 12, 2, 5)]                   # every material branch, deep bounces
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,kind,us,vs,n_lights,depth", PAIR_CASES)
+def test_pair_beam_on_equals_off_equals_oracle(rt, oracle, tmp_path, monkeypatch, scene, kind, us, vs, n_lights, depth):
+    """k_pair_beam (one beam per lit hit in front of k_shadow_shaft) decides most (hit, light) pairs without forming a sample ray; the frame,
+    the closest-hit ids and the sample-ray count must not depend on it: RT_ITEM_BEAM=2 (always) == RT_ITEM_BEAM=0 (never) == the oracle."""
+    import scenes_gen
+    if scene == "wavy":
+        path = scenes_gen.wavy_grid(str(tmp_path), n=96)
+    elif scene == "mixed":
+        path = scenes_gen.mixed_materials(str(tmp_path))
+    else:
+        path = os.path.join(SCENES, scene)
+    pts = [(-1.0, 1.0, 1.0), (0.8, 0.4, 1.5)][:n_lights]
+    w, h = 160, 100
+    if kind == "sphere":
+        off = rt.sphere_offsets(77, 0.3, us)
+        L = rt.set_sphere(rt.make_lights(points=pts, area=False), off)
+        oL = oracle.lights(area=False, points=pts)
+        oL.mode = 2
+        oL.n_offsets = us
+        oL.offsets = off.ctypes.data_as(C.POINTER(C.c_float))
+    else:
+        L = rt.make_lights(points=pts, area=True, usteps=us, vsteps=vs)
+        oL = oracle.lights(area=True, usteps=us, vsteps=vs, points=pts)
+    # a small leaf capacity makes a real tree of the generated scenes too (mixed at 16: 25 nodes, one of them lost, two unreachable faces)
+    cap = 1000 if scene.endswith((".obj", ".ply")) else (16 if scene == "mixed" else 64)
+    hs = rt.HostScene(path, cap, 15)
+    frames = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("RT_ITEM_BEAM", mode)
+        ctx = rt.Context(0)
+        ctx.upload(hs)
+        frames[mode] = _render_stats(rt, ctx, rt.default_camera(w, h), L, w, h, depth)
+        ctx.close()
+    (rgb, hits, st), (rgb0, hits0, st0) = frames["2"], frames["0"]
+    assert np.array_equal(hits, hits0) and np.array_equal(rgb.view(np.uint32), rgb0.view(np.uint32))
+    assert st.rays_sample == st0.rays_sample and st.rays_bounce == st0.rays_bounce and st.shaded_hits == st0.shaded_hits
+    assert st.rays_sample_walked < st0.rays_sample_walked, "the beams must decide some pairs"
+    osc = oracle.load_scene(path, cap, 15)
+    ref, rhits, _ = osc.render(oracle.camera(w, h), oL, w, h, max_depth=depth, threads=8, want_hits=True)
+    assert_exact(rgb, hits, ref, rhits)
+    osc.close(); hs.close()

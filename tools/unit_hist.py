@@ -63,6 +63,12 @@ if raw.size >= off + 65536 * 16:
         share = {n: round(float(coef[i] * u[:, 1 + i].sum() / cyc.sum()), 3) for i, n in enumerate(names)}
         share["unit"] = round(float(coef[8] * len(u) / cyc.sum()), 3)
         print("   share of the unit time:", share)
+        if u[:, 10].max() > 0:
+            nv = u[:, 10].astype(np.float64); no = u[:, 9].astype(np.float64)
+            for nm, m in (("all rays occluded", no == nv), ("no ray occluded", no == 0), ("mixed", (no > 0) & (no < nv))):
+                if m.any():
+                    print(f"   units with {nm}: {m.mean():.3f} of the units, {cyc[m].sum()/cyc.sum():.3f} of the time, mean kcycles {cyc[m].mean()/1e3:.1f}, groups {u[m,1].mean():.1f} "
+                          f"chunk-batches {u[m,4].mean():.1f} tri-shaft {u[m,6].mean():.1f} steps {u[m,7].mean()+u[m,8].mean():.1f}")
         for lo, hi in ((0, 50), (50, 90), (90, 99), (99, 100)):
             a, b = np.percentile(cyc, lo), np.percentile(cyc, hi)
             m = (cyc >= a) & (cyc <= b)
