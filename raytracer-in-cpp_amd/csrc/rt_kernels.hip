@@ -898,6 +898,9 @@ __device__ __forceinline__ void walk(const DNode &root, const DNode *__restrict_
 // The candidate set of every ray is unchanged: leaves are still entered only through the per-ray exact tests of the whole
 // ancestor chain (BoxTree::intersect, boxTree.cpp:150-173).
 // ======================================================================================================
+#ifndef RT_SHAFT_TRUNC
+#define RT_SHAFT_TRUNC 0.0185f        // the tip of the shaft that holds no counted point (t > 0.9815; 0: keep it)
+#endif
 struct ShaftLanes {
     float r[8];          // this lane's test (lane & 7): planes 0-5 (ax+, ax-, ay+, ay-, az+, az-, c, 2*margin); 6: near box (lo, hi); 7: far box
     float pad;           // padding of the tested boxes (>= the per-ray slab_pad of every segment of the unit); wave-uniform
@@ -910,7 +913,8 @@ struct ShaftLanes {
 // (ax, ay, az, c) with the third coefficient zero and split into positive / negative parts, so that
 //      min over the corners of a box = ax+ * lx + ax- * hx + ay+ * ly + ay- * hy + az+ * lz + az- * hz + c      (max: lo <-> hi)
 __device__ __forceinline__ ShaftLanes make_shaft_lanes(const int lane, const float hx, const float hy, const float hz, const float slx, const float sly,
-                                                       const float slz, const float shx, const float shy, const float shz, const float extent) {
+                                                       const float slz, const float shx, const float shy, const float shz, const float extent,
+                                                       const float trunc = 0.0f) {
     ShaftLanes SL;
     const int tk = lane & 7, proj = tk >> 1;
     const bool q1 = (tk & 1) != 0;
@@ -944,6 +948,16 @@ __device__ __forceinline__ ShaftLanes make_shaft_lanes(const int lane, const flo
     if (tk == 6) {          // near box: AABB of hull(S, h)
         SL.r[0] = fminf(slx, hx); SL.r[1] = fminf(sly, hy); SL.r[2] = fminf(slz, hz);
         SL.r[3] = fmaxf(shx, hx); SL.r[4] = fmaxf(shy, hy); SL.r[5] = fmaxf(shz, hz);
+        if (trunc > 0.0f) {
+            // ... without its TIP: where h lies beyond S along an axis (h_k < sl_k), a point p of a segment s -> h with p_k < h_k + trunc (sl_k - h_k)
+            // has t > 1 - trunc = 0.9815 on that segment -- lightStrikes counts t < 0.98 only.  The box then bounds every COUNTED point (content
+            // boxes, chunk bounds, the triangles' vertex boxes); it says nothing about where the rays run, so own boxes are not tested against it
+            // (shaft_lane_test: near_box = false).  m: far above the rounding of a computed point o + t d (~1e-7 |o|).
+            const float m = 1e-5f * scale;
+            SL.r[0] += hx < slx ? fmaxf(trunc * (slx - hx) - m, 0.0f) : 0.0f; SL.r[3] -= hx > shx ? fmaxf(trunc * (hx - shx) - m, 0.0f) : 0.0f;
+            SL.r[1] += hy < sly ? fmaxf(trunc * (sly - hy) - m, 0.0f) : 0.0f; SL.r[4] -= hy > shy ? fmaxf(trunc * (hy - shy) - m, 0.0f) : 0.0f;
+            SL.r[2] += hz < slz ? fmaxf(trunc * (slz - hz) - m, 0.0f) : 0.0f; SL.r[5] -= hz > shz ? fmaxf(trunc * (hz - shz) - m, 0.0f) : 0.0f;
+        }
     }
     if (tk == 7) {          // far box: AABB of the far cone { h + tau * (h - s) : s in S, tau >= 0 }
         SL.r[0] = hx >= shx ? hx : -3e38f; SL.r[1] = hy >= shy ? hy : -3e38f; SL.r[2] = hz >= shz ? hz : -3e38f;
@@ -955,13 +969,13 @@ __device__ __forceinline__ ShaftLanes make_shaft_lanes(const int lane, const flo
 // this lane's test on a padded box: near = the box is outside the near shaft by this test, far = outside the far cone by this test.
 // NaN anywhere compares false = keep.
 __device__ __forceinline__ void shaft_lane_test(const ShaftLanes &SL, const int tk, const float lx, const float ly, const float lz, const float hx, const float hy,
-                                                const float hz, bool &near_out, bool &far_out) {
+                                                const float hz, bool &near_out, bool &far_out, const bool near_box = true) {
     const float mn = __builtin_fmaf(SL.r[0], lx, __builtin_fmaf(SL.r[1], hx, __builtin_fmaf(SL.r[2], ly, __builtin_fmaf(SL.r[3], hy,
                      __builtin_fmaf(SL.r[4], lz, __builtin_fmaf(SL.r[5], hz, SL.r[6]))))));
     const float mx = __builtin_fmaf(SL.r[0], hx, __builtin_fmaf(SL.r[1], lx, __builtin_fmaf(SL.r[2], hy, __builtin_fmaf(SL.r[3], ly,
                      __builtin_fmaf(SL.r[4], hz, __builtin_fmaf(SL.r[5], lz, SL.r[6]))))));
     const bool box_out = (lx > SL.r[3]) || (hx < SL.r[0]) || (ly > SL.r[4]) || (hy < SL.r[1]) || (lz > SL.r[5]) || (hz < SL.r[2]);
-    near_out = tk < 6 ? (mn > 0.0f) : (tk == 6 && box_out);
+    near_out = tk < 6 ? (mn > 0.0f) : (tk == 6 && near_box && box_out);
     far_out = tk < 6 ? (mx + SL.r[7] < 0.0f) : (tk == 7 && box_out);
 }
 // byte j of a 64-bit ballot, for lane j < 8: does any of the 8 tests of child / chunk j say "outside"?
@@ -1341,7 +1355,7 @@ __device__ __forceinline__ void shaft_walk(const DNode *__restrict__ nodes, cons
         bool c_near, c_far, n_near, n_far;
         const ShaftLanes SL = shaft_lanes_load(sl.shaft, tk, SC);
         shaft_lane_test(SL, tk, ch.clo[0] - SL.pad, ch.clo[1] - SL.pad, ch.clo[2] - SL.pad, ch.chi[0] + SL.pad, ch.chi[1] + SL.pad, ch.chi[2] + SL.pad, c_near, c_far);
-        shaft_lane_test(SL, tk, ch.bmin[0] - SL.pad, ch.bmin[1] - SL.pad, ch.bmin[2] - SL.pad, ch.bmax[0] + SL.pad, ch.bmax[1] + SL.pad, ch.bmax[2] + SL.pad, n_near, n_far);
+        shaft_lane_test(SL, tk, ch.bmin[0] - SL.pad, ch.bmin[1] - SL.pad, ch.bmin[2] - SL.pad, ch.bmax[0] + SL.pad, ch.bmax[1] + SL.pad, ch.bmax[2] + SL.pad, n_near, n_far, false);
         const unsigned long long b_c = __ballot(c_near && ch.pad[1] == 0u), b_nn = __ballot(n_near), b_nf = __ballot(n_far);
         const bool culled = (SL.node_ok && ballot_byte_any(b_nn, lane) && ballot_byte_any(b_nf, lane)) || ballot_byte_any(b_c, lane);
         unsigned long long surv = __ballot(static_cast<uint32_t>(lane) < gcnt && !culled);       // bit j: child j survives
@@ -2779,7 +2793,7 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         const float srx = __builtin_amdgcn_rcpf(ddx), sry = __builtin_amdgcn_rcpf(ddy), srz = __builtin_amdgcn_rcpf(ddz);
         const unsigned long long vis_index = (static_cast<unsigned long long>(item_at) * static_cast<unsigned long long>(lslots) + static_cast<unsigned long long>(l)) * P + pass;
         if (!CONT) c_rays += static_cast<uint32_t>(__popcll(__ballot(valid)));      // wave-uniform: a scalar register, not a lane counter held (and spilled) across the walk
-        ShaftLanes SL = make_shaft_lanes(lane, hx, hy, hz, fminf(x0, x1), fminf(y0, y1), fminf(z0, z1), fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1), S.extent);
+        ShaftLanes SL = make_shaft_lanes(lane, hx, hy, hz, fminf(x0, x1), fminf(y0, y1), fminf(z0, z1), fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1), S.extent, RT_SHAFT_TRUNC);
         __builtin_amdgcn_wave_barrier();
         shaft_tri_store(sl.tri, lane, SL, hx, hy, hz, fminf(x0, x1), fminf(y0, y1), fminf(z0, z1), fmaxf(x0, x1), fmaxf(y0, y1), fmaxf(z0, z1));
         shaft_lanes_store(sl.shaft, lane, SL);
@@ -3096,7 +3110,7 @@ __device__ __forceinline__ bool beam_walk(const BeamCtx &B, const DScene &S, con
         bool culled = ballot_byte_any(b_c, lane);
         if (far_ok) {
             bool n_near, n_far;
-            shaft_lane_test(SLg, tk, ch.bmin[0] - SC.pad, ch.bmin[1] - SC.pad, ch.bmin[2] - SC.pad, ch.bmax[0] + SC.pad, ch.bmax[1] + SC.pad, ch.bmax[2] + SC.pad, n_near, n_far);
+            shaft_lane_test(SLg, tk, ch.bmin[0] - SC.pad, ch.bmin[1] - SC.pad, ch.bmin[2] - SC.pad, ch.bmax[0] + SC.pad, ch.bmax[1] + SC.pad, ch.bmax[2] + SC.pad, n_near, n_far, false);
             const unsigned long long b_nn = __ballot(n_near), b_nf = __ballot(n_far);
             culled = culled || (ballot_byte_any(b_nn, lane) && ballot_byte_any(b_nf, lane));
         }
@@ -3366,7 +3380,7 @@ void k_pair_beam(const DNode *__restrict__ nodes, const TriRec *__restrict__ tri
             if (L.mode == RT_LIGHT_SPHERE) sphere_box(L, px, py, pz, x0, y0, z0, x1, y1, z1);
             const float slx = fminf(x0, x1), sly = fminf(y0, y1), slz = fminf(z0, z1), shx = fmaxf(x0, x1), shy = fmaxf(y0, y1), shz = fmaxf(z0, z1);
             const float e = 1e-7f * S.extent;
-            ShaftLanes SL = make_shaft_lanes(lane, ax, ay, az, slx, sly, slz, shx, shy, shz, S.extent);
+            ShaftLanes SL = make_shaft_lanes(lane, ax, ay, az, slx, sly, slz, shx, shy, shz, S.extent, RT_SHAFT_TRUNC);
             shaft_inflate(SL, tk, e, e, e);
             const ShaftCtl SC{SL.pad, false};
             __builtin_amdgcn_wave_barrier();
