@@ -1370,7 +1370,8 @@ __device__ __forceinline__ void shaft_walk(const DNode *__restrict__ nodes, cons
             // scalar load (+4 %: 16 more live SGPRs -> spills) or through one VGPR with the queue looking one unit ahead (+6 %: the
             // other waves of the SIMD already cover that latency), the records of non-resident groups through an LDS slot instead of
             // v_readlane (+1.5 % on cfg4), 2x / 4x / 8x larger k_stage grids (0 %), two survivors per step as independent chains (round 3:
-            // +3 % dodge, +7 % cfg4 -- the second record's registers are spilled).
+            // +3 % dodge, +7 % cfg4 -- the second record's registers are spilled), the survivors in descending order (0.0 %: the any-hit walk
+            // does not care which child comes first).
             const DNode nd = resident ? sl.nodes[base + static_cast<uint32_t>(j)] : node_from_lane(ch, 8 * j);
             bool h = ((gm >> lane) & 1ull) != 0ull && !occluded;
             RT_PROF_ADD(lane, 74, __popcll(__ballot(h)));
@@ -3729,6 +3730,8 @@ __global__ __launch_bounds__(256) RT_SHADE_ATTR void k_shade(const DNode *__rest
                 const bool blocks = !SIMPLE && sample_blocks(L);
                 const uint32_t bpr = vst >> 3;
                 if (SIMPLE) word = vw[0];
+                // (unrolled by two at five waves per SIMD: 0.185 against 0.1865 ms -- noise; by two or four at four waves: +5 %.  The loop is not waiting on
+                //  its own dependency chains: what it lacks is issue slots -- FP64 at half rate, v_sqrt / v_rcp at quarter rate)
                 for (uint32_t s = 0; s < N; ++s) {
                     uint32_t bit = s & 63u;
                     if (!SIMPLE) {
