@@ -325,6 +325,7 @@ static void build_chunk_bounds(const rt_scene *sc, std::vector<uint32_t> &refs, 
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, max_edge = 0, bary_infl = 0;
             bool ok = !no_cull;
             uint32_t live_tris = 0;
+            double nsum[3] = {0, 0, 0}, nfirst[3] = {0, 0, 0};
             for (uint32_t i = 0; i < n && ok; ++i) {
                 const uint32_t f = r[c0 + i];
                 const float *v = sc->tri_verts + static_cast<size_t>(f) * 9;
@@ -347,6 +348,11 @@ static void build_chunk_bounds(const rt_scene *sc, std::vector<uint32_t> &refs, 
                 if (!(d00 > 0) || !(d11 > 0) || !(den > 1e-4 * d00 * d11)) { ok = false; break; }   // kappa = d00*d11/den <= 1e4
                 const double edge = std::sqrt(std::max(d00, d11));
                 max_edge = std::max(max_edge, edge);
+                // area-weighted mean normal (e1 x e0 has twice the area as its length), orientation of the chunk's first triangle
+                const double cr[3] = {e1[1] * e0[2] - e1[2] * e0[1], e1[2] * e0[0] - e1[0] * e0[2], e1[0] * e0[1] - e1[1] * e0[0]};
+                if (live_tris == 1) for (int k = 0; k < 3; ++k) nfirst[k] = cr[k];
+                const double sg = (cr[0] * nfirst[0] + cr[1] * nfirst[1] + cr[2] * nfirst[2]) < 0 ? -1.0 : 1.0;
+                for (int k = 0; k < 3; ++k) nsum[k] += sg * cr[k];
                 // (3): |error(u)|, |error(v)| <= ~20*eps*kappa = 1.2e-6*kappa  ->  in-plane growth 1.2e-6*kappa*edge (x4 safety)
                 bary_infl = std::max(bary_infl, 5e-6 * (d00 * d11 / den) * edge);
             }
@@ -358,13 +364,32 @@ static void build_chunk_bounds(const rt_scene *sc, std::vector<uint32_t> &refs, 
                 }
                 cb.never = 0.0f;
                 cb.infl = std::nextafter(static_cast<float>(infl), INFINITY);
+                // the slab: any unit direction gives a valid bound (the point of an accepted hit lies within infl per axis of its triangle, a
+                // convex combination of the vertices), the mean normal gives the thin one
+                double nl = std::sqrt(nsum[0] * nsum[0] + nsum[1] * nsum[1] + nsum[2] * nsum[2]);
+                double sn[3] = {0, 0, 1};
+                if (std::isfinite(nl) && nl > 1e-30) for (int k = 0; k < 3; ++k) sn[k] = nsum[k] / nl;
+                for (int k = 0; k < 3; ++k) cb.sn[k] = static_cast<float>(sn[k]);
+                double slo = 1e300, shi = -1e300;
+                for (uint32_t i = 0; i < n; ++i) {
+                    const uint32_t f = r[c0 + i];
+                    const float *v = sc->tri_verts + static_cast<size_t>(f) * 9;
+                    if (never_hit(v, sc->face_normal + static_cast<size_t>(f) * 3)) continue;
+                    for (int q = 0; q < 3; ++q) {
+                        const double dq = double(cb.sn[0]) * v[3 * q] + double(cb.sn[1]) * v[3 * q + 1] + double(cb.sn[2]) * v[3 * q + 2];
+                        slo = std::min(slo, dq); shi = std::max(shi, dq);
+                    }
+                }
+                const double sinfl = 1.0625 * (std::fabs(double(cb.sn[0])) + std::fabs(double(cb.sn[1])) + std::fabs(double(cb.sn[2]))) * double(cb.infl);
+                cb.slo = live_tris ? std::nextafter(static_cast<float>(slo - sinfl), -INFINITY) : -3e38f;
+                cb.shi = live_tris ? std::nextafter(static_cast<float>(shi + sinfl), INFINITY) : 3e38f;
             }
             if (ok && live_tris == 0) { for (int k = 0; k < 3; ++k) cb.lo[k] = cb.hi[k] = 1e30f; cb.infl = 0.0f; }     // nothing hittable inside: a far-away point
-            if (!ok) { cb = ChunkBound{}; cb.never = 2.0f; }
+            if (!ok) { cb = ChunkBound{}; cb.never = 2.0f; cb.slo = -3e38f; cb.shi = 3e38f; }
             out.push_back(cb);
         }
     }
-    if (out.empty()) { ChunkBound cb{}; cb.never = 2.0f; out.push_back(cb); }
+    if (out.empty()) { ChunkBound cb{}; cb.never = 2.0f; cb.slo = -3e38f; cb.shi = 3e38f; out.push_back(cb); }
 }
 
 // host-only: builds the chunk bounds of a flattened scene and reports {chunks, cullable chunks, leaves, max chunks per leaf}

@@ -43,8 +43,13 @@ struct alignas(16) ChunkBound {
     float lo[3], hi[3];      // AABB of the chunk's triangles, inflated
     float never;             // 0: the chunk may be culled; 2: never (ill-conditioned / degenerate / non-finite triangle inside)
     float infl;              // the inflation: the point of an accepted hit lies within `infl` (per axis) of the TRIANGLE it was accepted for
+    // the same bound along ONE more direction: sn . P lies in [slo, shi] for the point P of every accepted hit (sn: the chunk's mean face
+    // normal; the interval is the chunk's extent along it, inflated like the box).  A patch of a smooth surface is a thin plate in a fat
+    // axis-aligned box: rays that graze the surface cross the box and miss the plate.  Never-cullable chunks: sn = 0, (-3e38, 3e38).
+    float sn[3], slo, shi;
+    float pad_[3];
 };
-static_assert(sizeof(ChunkBound) == 32, "ChunkBound must be 32 bytes");
+static_assert(sizeof(ChunkBound) == 64, "ChunkBound must be 64 bytes");
 
 struct alignas(16) RayItem {     // a bounce ray (level >= 1) or an rt_trace_rays input ray
     float ox, oy, oz, dx;

@@ -1183,7 +1183,16 @@ __device__ __forceinline__ void shaft_leaf(const uint32_t ni, const uint32_t fir
                     const float t0z = (l2 - R.slab_pad - oz) * R.idz, t1z = (h2 + R.slab_pad - oz) * R.idz;
                     const float tin = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
                     const float tout = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-                    const bool miss = (tin > tout) || (tout < -1e-3f) || (tin > 0.981f);
+                    bool miss = (tin > tout) || (tout < -1e-3f) || (tin > 0.981f);
+#ifndef RT_NO_SLAB
+                    // ... and the chunk's slab (ChunkBound::sn): f(t) = sn . (o + t d) over the part of the line inside the box and the counted range;
+                    // a counted point has f in [slo, shi].  m: far above the rounding of the two dot products (~4e-7 (|o| + |d|) |sn|_1)
+                    const float n0 = lane_f(bd.sn[0], 8 * j), n1 = lane_f(bd.sn[1], 8 * j), n2 = lane_f(bd.sn[2], 8 * j);
+                    const float fa = __builtin_fmaf(n0, ox, __builtin_fmaf(n1, oy, n2 * oz)), fb = __builtin_fmaf(n0, dx, __builtin_fmaf(n1, dy, n2 * dz));
+                    const float f0 = __builtin_fmaf(fmaxf(tin, -1e-3f), fb, fa), f1 = __builtin_fmaf(fminf(tout, 0.981f), fb, fa);
+                    const float m = 0.04f * R.slab_pad;
+                    miss = miss || (fmaxf(f0, f1) + m < lane_f(bd.slo, 8 * j)) || (fminf(f0, f1) - m > lane_f(bd.shi, 8 * j));
+#endif
                     todo = live & ~__ballot(miss);
                 }
                 if (todo != 0ull) { RT_PROF_ADD(lane, 95, 1); todo_out = todo; return j; }

@@ -28,7 +28,7 @@ print("ms trace %.4f shadow %.4f shade %.4f total %.4f" % (st.ms_trace, st.ms_sh
 import numpy as np
 raw = np.fromfile(os.environ["RT_UNIT_DUMP"], dtype=np.uint32)
 U = raw[:4 * 65536 * 8].reshape(4, 65536, 8)
-Wv = raw[4 * 65536 * 8:].reshape(4, 16384, 4)
+Wv = raw[4 * 65536 * 8:4 * 65536 * 8 + 4 * 16384 * 4].reshape(4, 16384, 4)
 names = ["stage0 walk", "stage0 tasks", "stage1 walk", "stage1 tasks"]
 for k in range(4):
     u = U[k]; u = u[u[:, 0] > 0]
