@@ -63,6 +63,10 @@ COST = {
     "unit_flat": 355,            # flat k_shadow per unit: queue, item, h, shaft planes (~85), 8 triangles x 8 tests per step (2 x ~45 on the cube), plane rule, visibility word
     "unit_stack": 200,
     "unit_trace": 260,           # trace kernels per unit (a tile of 64 rays, or a leaf task): ray generation (Camera::screenToWorld in double), root tests, records / compaction
+    "pair_beam": 230,            # k_pair_beam per (hit, light): scalar item, shaft planes of the whole light, LDS records, direction check, visibility words / survivor buffer
+    "beam_group": 70,            # its group step: lane = (child, test) on content and own boxes (no per-ray tests)
+    "beam_chunk_batch": 60,      # 8 chunk bounds against the shaft
+    "beam_tri_chunk": 120,       # one chunk triangle by triangle (lane = triangle): tangent planes, near box, the plane rules over the interval of h.n
     "beam": 700,                 # k_beam per (tile of 64 hits, light) on a flat scene: items, wave min / max, planes, one leaf (chunk test + per-triangle test)
     "shade_sample": 170,         # k_shade per (tile of 64 hits, sample): light direction + reflection normalised (2 x sqrt, the three quotients of each share one reciprocal), glibc powf in double (branch-free: range and special answers are selects)
     "shade_tile": 1100,          # k_shade per tile: items, interpolated normal, eye vector, material, record; flat scenes: the child ray against the root leaf
@@ -141,6 +145,9 @@ def valu_model(work, flat, shaft):
             w["chunks_tested_per_ray"] * COST["chunk_per_ray"] + w["tri_shaft_tests"] * COST["tri_shaft_test"]
         # (the leaf-task launch runs the same leaf code and reports through the same counters)
         total += w["chunk_tests_stack_walk"] * 30
+        # the per-hit beam test in front of the units (lights of more than 64 samples): calibrated on cfg4, 1,051 modelled against 1,073 executed per beam
+        total += w.get("beams_tested", 0) * COST["pair_beam"] + w.get("beam_group_steps", 0) * COST["beam_group"] + \
+            w.get("beam_chunk_batches", 0) * COST["beam_chunk_batch"] + w.get("beam_chunks_tested_by_triangle", 0) * COST["beam_tri_chunk"]
         return useful, total
     useful += w["box_steps_stack_walk"] * COST["box_stack_walk"]
     return useful, useful + w["units"] * COST["unit_stack"] + w["chunk_tests_stack_walk"] * 30

@@ -113,7 +113,7 @@ def test_rocprof_kernel_stats_agree_with_the_event_times(scene, kernel):
     group for the gaps the event interval contains: under the profiler a launch boundary costs 5-6 us)."""
     rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"r03_{scene}_kernel_stats.csv"))))
     # the shadow GROUP of a level: beam test + walking launch (+ leaf-task launch); "k_shadow<true, ..." are the COUNT variants of the statistics frames
-    shadow = [r for r in rows if ("k_shadow" in r["Name"] or "k_beam" in r["Name"]) and "k_shadow<true" not in r["Name"]]
+    shadow = [r for r in rows if ("k_shadow" in r["Name"] or "k_beam" in r["Name"] or "k_pair_beam" in r["Name"]) and "k_shadow<true" not in r["Name"]]
     assert any(kernel in r["Name"] for r in shadow)
     bench = json.load(open(os.path.join(ROOT, "profiles", f"r03_bench_{scene}_under_rocprof.json")))
     rs = bench["roofline"] if bench["roofline"]["group"] == "shadow" else bench["roofline_shadow"]
