@@ -255,6 +255,10 @@ rt_status rt_host_scene_info(const rt_host_scene *hs, int32_t out[8], float root
 
 /* diagnostic, host only: {chunks, cullable chunks, leaves, max chunks per leaf} of the lanes=triangles chunk bounds   */
 rt_status rt_debug_chunk_stats(const rt_scene *scene, int32_t out[4]);
+/* diagnostic, host only: the bounds themselves -- 16 floats per chunk {lo[3], hi[3], never, infl, sn[3], slo, shi, 0, 0, 0} (box, slab along
+ * the chunk's mean normal) -- with the first chunk of every leaf (n_nodes words) and the leaf face references in chunk order (n_face_refs
+ * words).  bounds may be NULL to query *n_chunks.                                                                                         */
+rt_status rt_debug_chunk_bounds(const rt_scene *scene, float *bounds, int32_t cap_chunks, int32_t *n_chunks, uint32_t *leaf_chunk0, uint32_t *refs);
 
 /* diagnostic: wave-level step counters of the last frame, as executed by the shipped kernels (box-test steps, shaft steps, (ray, chunk)
  * triangle steps ...; layout in DESIGN.md 6).  Only the counting build librt_mi355x_work.so (same sources, -DRT_PROFILE_STEPS) fills them;

@@ -116,6 +116,7 @@ _SIGNATURES = [
     ("rt_host_scene_build_gpu", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     ("rt_host_scene_info", C.c_int, [C.c_void_p, _P(C.c_int32), _P(C.c_float)]),
     ("rt_debug_chunk_stats", C.c_int, [_P(rt_scene), _P(C.c_int32)]),
+    ("rt_debug_chunk_bounds", C.c_int, [_P(rt_scene), _P(C.c_float), C.c_int32, _P(C.c_int32), _P(C.c_uint32), _P(C.c_uint32)]),
     ("rt_debug_work_counters", C.c_int, [C.c_void_p, _P(C.c_uint64), C.c_int32]),
     ("rt_default_camera", None, [_P(rt_camera), C.c_int32, C.c_int32]),
     ("rt_yaw_camera", None, [_P(rt_camera), C.c_int32, C.c_int32, C.c_float]),

@@ -413,6 +413,28 @@ extern "C" rt_status rt_debug_chunk_stats(const rt_scene *sc, int32_t out[4]) {
     return RT_OK;
 }
 
+// host-only: the chunk bounds themselves, 16 floats per chunk {lo[3], hi[3], never, infl, sn[3], slo, shi, 0, 0, 0}, the per-node index of a
+// leaf's first chunk and the leaf face references in the order the chunks hold them (tests/test_host_scene.py checks the containment the
+// culling rules rely on)
+extern "C" rt_status rt_debug_chunk_bounds(const rt_scene *sc, float *bounds, int32_t cap_chunks, int32_t *n_chunks, uint32_t *leaf_chunk0_out, uint32_t *refs_out) {
+    if (!sc || !sc->nodes || !n_chunks) return RT_ERR_INVALID;
+    std::vector<uint32_t> refs(sc->face_refs, sc->face_refs + sc->n_face_refs);
+    std::vector<uint32_t> leaf_chunk0(sc->n_nodes, 0u);
+    std::vector<ChunkBound> cbs;
+    float extent = 0.f;
+    for (size_t i = 0; i < static_cast<size_t>(sc->n_faces) * 9; ++i) extent = std::fmax(extent, std::fabs(sc->tri_verts[i]));
+    build_chunk_bounds(sc, refs, leaf_chunk0, cbs, extent, false);
+    *n_chunks = static_cast<int32_t>(cbs.size());
+    if (bounds) {
+        if (cap_chunks < *n_chunks) return RT_ERR_INVALID;
+        static_assert(sizeof(ChunkBound) == 16 * sizeof(float), "ChunkBound is 16 floats");
+        std::memcpy(bounds, cbs.data(), cbs.size() * sizeof(ChunkBound));
+    }
+    if (leaf_chunk0_out) std::memcpy(leaf_chunk0_out, leaf_chunk0.data(), leaf_chunk0.size() * sizeof(uint32_t));
+    if (refs_out) std::memcpy(refs_out, refs.data(), refs.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
 extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
     if (!c) return RT_ERR_INVALID;
     if (!sc || !sc->nodes || sc->n_nodes == 0 || !sc->materials || sc->n_materials == 0) { c->err = "rt_upload_scene: empty scene"; return RT_ERR_INVALID; }

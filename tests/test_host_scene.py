@@ -258,3 +258,57 @@ def test_malformed_ply_files_are_refused(rt, tmp_path):
            "element face 1\nproperty list uint int vertex_indices\nend_header\n").encode()
     b.write_bytes(hdr + struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0) + struct.pack("<I3i", 0xFFFFFFF0, 0, 1, 2))
     assert lib.rt_host_scene_load(str(b).encode(), 1000, 15, C.byref(h)) == rt.capi.RT_ERR_IO
+
+
+@pytest.mark.parametrize("name", ["dodgeColorTest.obj", "bunny.ply", "wavy"])
+def test_chunk_boxes_and_slabs_contain_their_triangles(rt, scenes, tmp_path, name):
+    """What the exact-culling rules rely on (rt_capi.cpp: build_chunk_bounds): every cullable chunk's inflated box AND its slab along the
+    chunk's mean normal contain all vertices of its hittable triangles, with at least `infl` (per axis, resp. sum |sn_k| infl) to spare --
+    the computed point of an accepted hit lies within infl of its triangle.  And the slab is what it is for: on smooth meshes it is several
+    times thinner than the box is along the slab's direction.  CPU only."""
+    import ctypes as C
+    import scenes_gen
+    lib = rt.load_library()
+    path = scenes_gen.wavy_grid(str(tmp_path), n=96) if name == "wavy" else os.path.join(scenes, name)
+    hs = rt.HostScene(path, 1000, 15)
+    v = hs.view
+    n = C.c_int32()
+    assert lib.rt_debug_chunk_bounds(C.byref(v), None, 0, C.byref(n), None, None) == 0 and n.value > 0
+    b = np.zeros((n.value, 16), np.float32)
+    chunk0 = np.zeros(v.n_nodes, np.uint32)
+    refs = np.zeros(v.n_face_refs, np.uint32)
+    assert lib.rt_debug_chunk_bounds(C.byref(v), b.ctypes.data_as(C.POINTER(C.c_float)), n.value, C.byref(n), chunk0.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                     refs.ctypes.data_as(C.POINTER(C.c_uint32))) == 0
+    a = hs.arrays()
+    tv = a["tri_verts"].reshape(-1, 3, 3).astype(np.float64)
+    thin = []
+    checked = 0
+    for ni in range(v.n_nodes):
+        cf = int(a["node_count_flags"][ni])
+        if not cf & 0x80000000:
+            continue
+        cnt, first = cf & 0x7FFFFFFF, int(a["node_first"][ni])
+        for c in range((cnt + 63) // 64):
+            cb = b[int(chunk0[ni]) + c].astype(np.float64)
+            if cb[6] >= 1.5:
+                assert cb[11] <= -1e38 and cb[12] >= 1e38                    # never cullable: the slab rejects nothing either
+                continue
+            faces = refs[first + 64 * c:first + min(cnt, 64 * c + 64)]
+            P = tv[faces].reshape(-1, 3)
+            edges = np.abs(tv[faces][:, 1] - tv[faces][:, 0]).sum(1) + np.abs(tv[faces][:, 2] - tv[faces][:, 0]).sum(1)
+            P = P[np.repeat(edges > 0, 3)] if (edges > 0).any() else P       # (triangles that can never be hit need no bound; keep it simple: degenerate points)
+            infl, sn = cb[7], cb[8:11]
+            assert abs(np.linalg.norm(sn) - 1.0) < 1e-5
+            d = P @ sn
+            sinfl = np.abs(sn).sum() * infl
+            if len(P):
+                assert (P >= cb[0:3] + 0.99 * infl).all() and (P <= cb[3:6] - 0.99 * infl).all()
+                assert d.min() >= cb[11] + 0.99 * sinfl and d.max() <= cb[12] - 0.99 * sinfl
+                checked += 1
+                # the box's extent along sn against the slab's thickness
+                thin.append((np.abs(sn) * (cb[3:6] - cb[0:3])).sum() / max(cb[12] - cb[11], 1e-30))
+    assert checked > 20
+    print(name, "box extent along sn / slab thickness: median %.2f, p90 %.2f" % (np.median(thin), np.percentile(thin, 90)))
+    if name != "dodgeColorTest.obj":
+        assert np.median(thin) > 1.5, np.median(thin)                          # smooth surfaces: thin plates in fat boxes
+    hs.close()
