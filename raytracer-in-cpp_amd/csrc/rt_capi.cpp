@@ -292,6 +292,27 @@ static bool never_hit(const float *v, const float *nn) {
     return !std::isfinite(inv);
 }
 
+// A triangle the chunk bounds cannot vouch for: non-finite, a face normal that is not unit, or a barycentric solve conditioned worse than
+// kappa = d00 d11 / denom = 1e4 (edges from vertex A, as the reference sets it up).  Its computed hit points are not tied to the triangle, so
+// no region bounds them: the chunk that holds it is never culled as a whole and the triangle itself never by the per-triangle shaft test
+// (TriRec::flags bit 1).  Otherwise: the in-plane growth (3) of the error analysis above and the longer of its two edges.
+static bool tri_ill_conditioned(const float *v, const float *nn, double &edge, double &bary_infl) {
+    edge = 0; bary_infl = 0;
+    for (int k = 0; k < 9; ++k) if (!std::isfinite(v[k])) return true;
+    const double nl = std::sqrt(double(nn[0]) * nn[0] + double(nn[1]) * nn[1] + double(nn[2]) * nn[2]);
+    if (!std::isfinite(nl) || std::fabs(nl - 1.0) > 1e-3) return true;   // Face::normal is unit unless degenerate
+    double e0[3], e1[3];
+    for (int k = 0; k < 3; ++k) { e0[k] = double(v[6 + k]) - v[k]; e1[k] = double(v[3 + k]) - v[k]; }
+    const double d00 = e0[0] * e0[0] + e0[1] * e0[1] + e0[2] * e0[2], d11 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2];
+    const double d01 = e0[0] * e1[0] + e0[1] * e1[1] + e0[2] * e1[2];
+    const double den = d00 * d11 - d01 * d01;
+    if (!(d00 > 0) || !(d11 > 0) || !(den > 1e-4 * d00 * d11)) return true;   // kappa = d00*d11/den <= 1e4
+    edge = std::sqrt(std::max(d00, d11));
+    // (3): |error(u)|, |error(v)| <= ~20*eps*kappa = 1.2e-6*kappa  ->  in-plane growth 1.2e-6*kappa*edge (x4 safety)
+    bary_infl = 5e-6 * (d00 * d11 / den) * edge;
+    return false;
+}
+
 static void build_chunk_bounds(const rt_scene *sc, std::vector<uint32_t> &refs, std::vector<uint32_t> &leaf_chunk0,
                                std::vector<ChunkBound> &out, float extent, bool no_cull) {
     for (uint32_t ni = 0; ni < sc->n_nodes; ++ni) {
@@ -326,35 +347,27 @@ static void build_chunk_bounds(const rt_scene *sc, std::vector<uint32_t> &refs, 
             bool ok = !no_cull;
             uint32_t live_tris = 0;
             double nsum[3] = {0, 0, 0}, nfirst[3] = {0, 0, 0};
-            for (uint32_t i = 0; i < n && ok; ++i) {
+            for (uint32_t i = 0; i < n; ++i) {
                 const uint32_t f = r[c0 + i];
                 const float *v = sc->tri_verts + static_cast<size_t>(f) * 9;
                 const float *nn = sc->face_normal + static_cast<size_t>(f) * 3;
                 if (never_hit(v, nn)) continue;         // cannot be hit by any ray AS THE REFERENCE COMPUTES IT: no bound needed for it
+                double edge, binfl;
+                if (tri_ill_conditioned(v, nn, edge, binfl)) { ok = false; continue; }      // (the well-conditioned ones still get their inflation: below)
                 ++live_tris;
-                for (int k = 0; k < 9; ++k) if (!std::isfinite(v[k])) ok = false;
-                const double nl = std::sqrt(double(nn[0]) * nn[0] + double(nn[1]) * nn[1] + double(nn[2]) * nn[2]);
-                if (!std::isfinite(nl) || std::fabs(nl - 1.0) > 1e-3) { ok = false; break; }   // Face::normal is unit unless degenerate
                 for (int k = 0; k < 3; ++k) {
                     lo[k] = std::min(lo[k], double(std::min(v[k], std::min(v[3 + k], v[6 + k]))));
                     hi[k] = std::max(hi[k], double(std::max(v[k], std::max(v[3 + k], v[6 + k]))));
                 }
-                // conditioning of the barycentric solve exactly as the reference sets it up (edges from vertex A)
+                max_edge = std::max(max_edge, edge);
+                bary_infl = std::max(bary_infl, binfl);
+                // area-weighted mean normal (e1 x e0 has twice the area as its length), orientation of the chunk's first triangle
                 double e0[3], e1[3];
                 for (int k = 0; k < 3; ++k) { e0[k] = double(v[6 + k]) - v[k]; e1[k] = double(v[3 + k]) - v[k]; }
-                const double d00 = e0[0] * e0[0] + e0[1] * e0[1] + e0[2] * e0[2], d11 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2];
-                const double d01 = e0[0] * e1[0] + e0[1] * e1[1] + e0[2] * e1[2];
-                const double den = d00 * d11 - d01 * d01;
-                if (!(d00 > 0) || !(d11 > 0) || !(den > 1e-4 * d00 * d11)) { ok = false; break; }   // kappa = d00*d11/den <= 1e4
-                const double edge = std::sqrt(std::max(d00, d11));
-                max_edge = std::max(max_edge, edge);
-                // area-weighted mean normal (e1 x e0 has twice the area as its length), orientation of the chunk's first triangle
                 const double cr[3] = {e1[1] * e0[2] - e1[2] * e0[1], e1[2] * e0[0] - e1[0] * e0[2], e1[0] * e0[1] - e1[1] * e0[0]};
                 if (live_tris == 1) for (int k = 0; k < 3; ++k) nfirst[k] = cr[k];
                 const double sg = (cr[0] * nfirst[0] + cr[1] * nfirst[1] + cr[2] * nfirst[2]) < 0 ? -1.0 : 1.0;
                 for (int k = 0; k < 3; ++k) nsum[k] += sg * cr[k];
-                // (3): |error(u)|, |error(v)| <= ~20*eps*kappa = 1.2e-6*kappa  ->  in-plane growth 1.2e-6*kappa*edge (x4 safety)
-                bary_infl = std::max(bary_infl, 5e-6 * (d00 * d11 / den) * edge);
             }
             if (ok) {
                 const double infl = bary_infl + 1e-3 * max_edge + 1e-4 * extent;
@@ -385,7 +398,13 @@ static void build_chunk_bounds(const rt_scene *sc, std::vector<uint32_t> &refs, 
                 cb.shi = live_tris ? std::nextafter(static_cast<float>(shi + sinfl), INFINITY) : 3e38f;
             }
             if (ok && live_tris == 0) { for (int k = 0; k < 3; ++k) cb.lo[k] = cb.hi[k] = 1e30f; cb.infl = 0.0f; }     // nothing hittable inside: a far-away point
-            if (!ok) { cb = ChunkBound{}; cb.never = 2.0f; cb.slo = -3e38f; cb.shi = 3e38f; }
+            if (!ok) {
+                // never culled as a whole; its well-conditioned triangles keep THEIR inflation for the per-triangle shaft test of the shadow units
+                // (0: there is none -- no_cull, or every triangle of the chunk is ill-conditioned)
+                const double infl = bary_infl + 1e-3 * max_edge + 1e-4 * extent;
+                cb = ChunkBound{}; cb.never = 2.0f; cb.slo = -3e38f; cb.shi = 3e38f;
+                cb.infl = (!no_cull && live_tris) ? std::nextafter(static_cast<float>(infl), INFINITY) : 0.0f;
+            }
             out.push_back(cb);
         }
     }
@@ -492,7 +511,8 @@ extern "C" rt_status rt_upload_scene(rt_ctx *c, const rt_scene *sc) {
         r.d00 = dot(e0, e0); r.d01 = dot(e0, e1); r.d11 = dot(e1, e1);
         r.inv_denom = 1 / (r.d00 * r.d11 - r.d01 * r.d01);
         r.face = f;
-        r.flags = sc->materials[sc->mat_id[f]].illum == 9 ? 1u : 0u;
+        double edge_, binfl_;
+        r.flags = (sc->materials[sc->mat_id[f]].illum == 9 ? 1u : 0u) | ((!never_hit(v, n) && tri_ill_conditioned(v, n, edge_, binfl_)) ? 2u : 0u);
         r.pad = 0u;
     }
     c->reflective = false;

@@ -1214,11 +1214,14 @@ __device__ __forceinline__ void shaft_leaf(const uint32_t ni, const uint32_t fir
             unsigned long long todo = todo_cur & live;
             const uint32_t m_rays = static_cast<uint32_t>(__popcll(todo));
             unsigned long long tmask = ~0ull;
-            if (m_rays >= RT_TRI_SHAFT_MIN && lane_f(bd.never, 8 * cur) < 1.5f) {
+            // (a chunk that is never culled as a whole still carries the inflation of its well-conditioned triangles -- 0: it has none --; the
+            //  ill-conditioned ones, TriRec::flags bit 1, are kept whatever the test says: dodge's collinear slivers sit one or two to a chunk and
+            //  used to cost 64 rays x 64 triangles wherever a unit entered their leaf)
+            if (m_rays >= RT_TRI_SHAFT_MIN && (lane_f(bd.never, 8 * cur) < 1.5f || lane_f(bd.infl, 8 * cur) > 0.0f)) {
                 // lane = triangle: which triangles of the chunk can be hit by ANY ray of the unit
                 RT_PH(sl, 4);
                 __builtin_amdgcn_wave_barrier();
-                hast = hast && !tri_outside_shaft(srec, tr, lane_f(bd.infl, 8 * cur) * 1.0625f);
+                hast = hast && ((tr.flags & 2u) != 0u || !tri_outside_shaft(srec, tr, lane_f(bd.infl, 8 * cur) * 1.0625f));
                 tmask = __ballot(hast);
                 RT_PROF_ADD(lane, 70, 1); RT_PROF_ADD(lane, 71, __popcll(tmask)); RT_PROF_ADD(lane, 72, m_rays); RT_PROF_ADD(lane, 73, tmask == 0ull ? 1 : 0);
             }
