@@ -73,3 +73,7 @@ if raw.size >= off + 65536 * 16:
             a, b = np.percentile(cyc, lo), np.percentile(cyc, hi)
             m = (cyc >= a) & (cyc <= b)
             print(f"   units p{lo}-p{hi}: share of time {cyc[m].sum()/cyc.sum():.2f}, mean groups {u[m,1].mean():.1f} children-hit {u[m,3].mean():.1f} chunk-batches {u[m,4].mean():.1f} tri-shaft {u[m,6].mean():.1f} steps {u[m,7].mean()+u[m,8].mean():.1f}")
+        order = np.argsort(-cyc)[:12]
+        print("   longest shaft units (kcycles | groups, shaft-survivors, children-hit, chunk-batches, chunks-with-work, tri-shaft-tests, ray-mode-tri, (ray,chunk)-steps | occluded, valid):")
+        for i in order:
+            print("     ", f"{cyc[i]/1e3:8.1f}", u[i, 1:9].tolist(), u[i, 9:11].tolist())
