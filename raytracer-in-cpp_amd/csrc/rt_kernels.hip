@@ -56,9 +56,14 @@ __device__ __forceinline__ void normalize3(float &x, float &y, float &z) {
 // test is wave-uniform, so the common case has no divergent branch.  (k_shade runs two of these per sample.)
 __device__ __forceinline__ void normalize3_shared(float &x, float &y, float &z) {
     const float q = x * x + (y * y + z * z);
-    const float s = sqrtf(q);
-    const bool ok = (s >= 0x1p-40f) && (s <= 0x1p40f) && (fminf(fminf(fabsf(x), fabsf(y)), fabsf(z)) >= 0x1p-60f);     // NaN: false
+    const bool ok = (q >= 0x1p-80f) && (q <= 0x1p80f) && (fminf(fminf(fabsf(x), fabsf(y)), fabsf(z)) >= 0x1p-60f);     // NaN: false
     if (__ballot(!ok) == 0ull) {
+        // the correctly rounded square root as hipcc expands sqrtf -- v_sqrt_f32 (1 ulp), then the neighbour whose residual says so -- without the
+        // scaling of denormal arguments and the 0 / inf pass-through, neither of which this range can need: 9 instead of 16 instructions
+        float s = __builtin_amdgcn_sqrtf(q);
+        const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+        const float rm = __builtin_fmaf(-sm, s, q), rp = __builtin_fmaf(-sp, s, q);
+        s = rp > 0.0f ? sp : (rm <= 0.0f ? sm : s);
         float r = __builtin_amdgcn_rcpf(s);
         const float e = __builtin_fmaf(-s, r, 1.0f);
         r = __builtin_fmaf(e, r, r);
@@ -70,6 +75,7 @@ __device__ __forceinline__ void normalize3_shared(float &x, float &y, float &z) 
         y = __builtin_fmaf(__builtin_fmaf(-s, qy, y), r, qy);
         z = __builtin_fmaf(__builtin_fmaf(-s, qz, z), r, qz);
     } else if (q > 0.0f) {
+        const float s = sqrtf(q);
         x = x / s; y = y / s; z = z / s;
     }
 }
