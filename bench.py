@@ -68,7 +68,7 @@ COST = {
     "beam_chunk_batch": 60,      # 8 chunk bounds against the shaft
     "beam_tri_chunk": 120,       # one chunk triangle by triangle (lane = triangle): tangent planes, near box, the plane rules over the interval of h.n
     "beam": 700,                 # k_beam per (tile of 64 hits, light) on a flat scene: items, wave min / max, planes, one leaf (chunk test + per-triangle test)
-    "shade_sample": 170,         # k_shade per (tile of 64 hits, sample): light direction + reflection normalised (2 x sqrt, the three quotients of each share one reciprocal), glibc powf in double (branch-free: range and special answers are selects)
+    "shade_sample": 151,         # k_shade per (tile of 64 hits, sample): light direction + reflection normalised (2 x sqrt, the three quotients of each share one reciprocal), glibc powf in double (branch-free: range and special answers are selects)
     "shade_tile": 1100,          # k_shade per tile: items, interpolated normal, eye vector, material, record; flat scenes: the child ray against the root leaf
 }
 
@@ -268,11 +268,12 @@ def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, c
         roof.update({"achieved": None, "frac": None, "note": "no counting pass (--no-work-counters, or librt_mi355x_work.so missing: run __graft_entry__.build())"})
     ent, why = pmc_constant("valu.json", scene, cfg, sha)
     if ent:
-        insts = sum(v["valu_wave_instructions"] for k, v in ent["kernels"].items() if "k_shadow" in k)
+        in_group = lambda k: "k_shadow" in k or "k_beam" in k or "k_pair_beam" in k          # every kernel the shadow interval of the events contains
+        insts = sum(v["valu_wave_instructions"] for k, v in ent["kernels"].items() if in_group(k))
         r = insts / (ms_shadow_frame * 1e6) / N_SIMDS
         roof["executed_valu"] = {"constant": True, "wave_instructions_per_frame_level0": int(insts), "per_simd_per_ns": round(r, 4),
                                  "frac": round(r / VALU_PEAK_PER_SIMD_NS, 4), "source": ent["how"]}
-        roof["executed_valu"].update(clock_independent(ent["kernels"], lambda k: "k_shadow" in k))
+        roof["executed_valu"].update(clock_independent(ent["kernels"], in_group))
     else:
         roof["executed_valu"] = {"constant": True, "frac": None, "why": why}
     ent, why = pmc_constant("traffic.json", scene, cfg, sha)
