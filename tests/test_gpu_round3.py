@@ -329,3 +329,31 @@ def test_pair_beam_on_equals_off_equals_oracle(rt, oracle, tmp_path, monkeypatch
     ref, rhits, _ = osc.render(oracle.camera(w, h), oL, w, h, max_depth=depth, threads=8, want_hits=True)
     assert_exact(rgb, hits, ref, rhits)
     osc.close(); hs.close()
+
+
+@pytest.mark.gpu
+def test_graph_replay_with_pair_beams_in_the_captured_frame(rt, oracle):
+    """A tree scene under a 16 x 16 light: the captured launch sequence holds k_pair_beam + k_shadow_shaft over the survivor list at every level.
+    Twelve replays with a yawing camera: frames 0, 5 and 11 equal the oracle bit for bit, and a replay equals the eager frame of its camera."""
+    w, h, depth = 240, 136, 3
+    path = os.path.join(SCENES, "dodgeColorTest.obj")
+    hs = rt.HostScene(path, 1000, 15)
+    ctx = rt.Context(0)
+    ctx.upload(hs)
+    L = rt.make_lights(area=True, usteps=16, vsteps=16)
+    p = rt.make_params(w, h, depth)
+    out = rt.hipmem.DeviceBuffer(h * w * 3 * 4)
+    g = rt.FrameGraph(ctx, L, p, out.address, 0)
+    osc = oracle.load_scene(path)
+    for f in range(12):
+        yaw = float(np.float32(0.05 * f))
+        g.launch(rt.default_camera(w, h, yaw))
+        if f in (0, 5, 11):
+            st = g.stats()                                   # synchronises
+            got = out.to_numpy(np.float32, (h, w, 3))
+            ref, _, _ = osc.render(oracle.camera(w, h, yaw), oracle.lights(area=True, usteps=16, vsteps=16), w, h, max_depth=depth, threads=8)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (f, float(np.abs(got - ref).max()))
+            assert 0 < st.rays_sample_walked < st.rays_sample            # the beams decided pairs inside the replayed graph too
+    eager, _ = render_gpu(rt, ctx, rt.default_camera(w, h, float(np.float32(0.05 * 11))), L, w, h, depth)
+    assert np.array_equal(out.to_numpy(np.float32, (h, w, 3)).view(np.uint32), eager.view(np.uint32))
+    g.close(); out.free(); osc.close(); ctx.close(); hs.close()
