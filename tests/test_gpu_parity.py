@@ -437,11 +437,11 @@ def test_random_soups_match_oracle(rt, oracle, tmp_path, seed, n_tri, cap):
     """Fuzz parity: seeded triangle soups (clusters, slivers with aspect up to 1e6, zero-area and duplicated triangles, shared
     vertices, every material kind) through the same loader / octree builder at several leaf capacities -- deep trees, one big
     leaf, and flat scenes of 12 and 40 arbitrary triangles for the plane culling.  GPU vs oracle (face ids exact, RGB <= 1e-5)
-    for a 9-sample and a 64-sample light, and culled vs RT_NO_CULL=1 bit for bit.  Parity with the reference itself is
-    unpinned for these scenes (no reference output exists)."""
+    for a 9-sample, a 64-sample and a 256-sample light (four passes: the per-hit beam test k_pair_beam on the trees, blocks of 8 x 8 samples),
+    and culled vs RT_NO_CULL=1 bit for bit.  Parity with the reference itself is unpinned for these scenes (no reference output exists)."""
     path = scenes_gen.random_soup(str(tmp_path), seed, n_tri)
     osc = oracle.load_scene(path, capacity=cap)
-    for (w, h, u, depth, yaw) in [(128, 96, 3, 3, 0.0), (72, 56, 8, 2, 0.9)]:
+    for (w, h, u, depth, yaw) in [(128, 96, 3, 3, 0.0), (72, 56, 8, 2, 0.9), (64, 48, 16, 2, 0.4)]:
         frames = []
         for no_cull in (False, True):
             if no_cull:
