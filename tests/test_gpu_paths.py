@@ -93,14 +93,14 @@ def test_model_matrix_with_and_without_rebuild(rt, oracle, scene, rebuild):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("s", [1000.0, 0.001])
-@pytest.mark.parametrize("scene", ["cube.obj", "dodgeColorTest.obj"])
-def test_scene_scale_1e3_and_1e_minus_3(rt, oracle, scene, s, monkeypatch):
+@pytest.mark.parametrize("scene,u", [("cube.obj", 8), ("dodgeColorTest.obj", 8), ("dodgeColorTest.obj", 16)])       # 16 x 16: four passes, k_pair_beam in front of the units
+def test_scene_scale_1e3_and_1e_minus_3(rt, oracle, scene, u, s, monkeypatch):
     """Every culling margin (content / chunk boxes, shaft planes, plane culling, the verified slab test) is relative to the scene's
     extent: a scene scaled by 1e3 or 1e-3 (model matrix, tree rebuilt) with camera and light scaled along must give the oracle's frame
     bit for bit, and the culled render must equal the RT_NO_CULL=1 render."""
     path = os.path.join(SCENES, scene)
     m = [s, 0.0, 0.0, 0.0, 0.0, s, 0.0, 0.0, 0.0, 0.0, s, 0.0]
-    w, h, u = 176, 128, 8
+    w, h = (176, 128) if u == 8 else (120, 88)
     cam, ocam, L, oL = scaled_camera_and_lights(rt, oracle, w, h, s, u)
     hs = rt.HostScene(path, 1000, 15)
     hs.set_model(m, True)
