@@ -357,3 +357,33 @@ def test_graph_replay_with_pair_beams_in_the_captured_frame(rt, oracle):
     eager, _ = render_gpu(rt, ctx, rt.default_camera(w, h, float(np.float32(0.05 * 11))), L, w, h, depth)
     assert np.array_equal(out.to_numpy(np.float32, (h, w, 3)).view(np.uint32), eager.view(np.uint32))
     g.close(); out.free(); osc.close(); ctx.close(); hs.close()
+
+
+LIGHT_SPOTS = [(0.0, 0.0, 0.3), (0.3, 0.1, 0.05), (-0.4, 0.2, -0.1), (0.0, 0.45, 0.0), (40.0, 25.0, 60.0), (-0.9, -0.9, 0.02), (0.05, 0.02, 1.0e-3)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("us", [8, 16])
+@pytest.mark.parametrize("spot", LIGHT_SPOTS)
+def test_lights_inside_close_to_and_far_from_the_model(rt, oracle, spot, us, monkeypatch):
+    """The shaft constructions (tangent planes through the hit, the near box without its tip, the far cone, the chunk slabs) with the light where
+    they degenerate: inside the model's bounding box, a hair above a surface, level with the hits along an axis (no tip to cut, no tangent in a
+    projection), far outside.  Culled == RT_NO_CULL=1 == oracle, one pass (units only) and four passes (k_pair_beam)."""
+    path = os.path.join(SCENES, "dodgeColorTest.obj")
+    hs = rt.HostScene(path, 1000, 15)
+    w, h, depth = 128, 80, 2
+    L = rt.make_lights(points=[spot], area=True, usteps=us, vsteps=us)
+    frames = []
+    for no_cull in (False, True):
+        if no_cull:
+            monkeypatch.setenv("RT_NO_CULL", "1")
+        ctx = rt.Context(0)
+        ctx.upload(hs)
+        frames.append(render_gpu(rt, ctx, rt.default_camera(w, h), L, w, h, depth))
+        ctx.close()
+    monkeypatch.delenv("RT_NO_CULL", raising=False)
+    assert np.array_equal(frames[0][1], frames[1][1]) and np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32))
+    osc = oracle.load_scene(path)
+    ref, rhits, _ = osc.render(oracle.camera(w, h), oracle.lights(area=True, usteps=us, vsteps=us, points=[spot]), w, h, max_depth=depth, threads=8, want_hits=True)
+    assert_exact(frames[0][0], frames[0][1], ref, rhits)
+    osc.close(); hs.close()
