@@ -21,13 +21,14 @@ void launch_trace(bool primary, bool count, bool flat, int grid, hipStream_t st,
 void launch_shadow(bool count, bool flat, int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots,
                    uint32_t item_cap, const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target, const uint32_t *sidx);
 void launch_shadow_shaft(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots, uint32_t item_cap,
-                         const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target, const uint32_t *sidx);
+                         const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target, const uint32_t *sidx,
+                         const uint8_t *pair_done);
 void launch_shadow_shaft_cont(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, uint32_t item_cap, const ShadeItem *items,
                               Control *ctl, unsigned long long *vis, const ContTask *tasks_in, uint32_t cap, const uint32_t *sidx);
 void launch_beam(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, uint32_t item_cap, const ShadeItem *items, Control *ctl,
                  unsigned long long *vis, uint32_t *sidx);
 void launch_pair_beam(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, uint32_t item_cap, const ShadeItem *items, Control *ctl,
-                      unsigned long long *vis, uint32_t *sidx);
+                      unsigned long long *vis, uint32_t *sidx, uint8_t *done);
 void launch_shadow_cont(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, uint32_t item_cap, const ShadeItem *items,
                         Control *ctl, unsigned long long *vis, const ContTask *tasks_in, ContTask *tasks_out, uint32_t q_in, uint32_t q_out,
                         uint32_t cap, uint32_t budget, const uint32_t *sidx);
@@ -78,6 +79,8 @@ struct rt_ctx {
     ShadeItem *d_items = nullptr;
     unsigned long long *d_vis = nullptr;
     uint32_t *d_sidx = nullptr;           // k_beam's survivors: item storage indices, 16 sub-lists like d_items
+    uint8_t *d_done = nullptr;            // k_pair_beam with several lights: one byte per (item slot, light)
+    size_t cap_done = 0;
     unsigned long long *d_best = nullptr, *d_lit = nullptr;   // staged trace of tree scenes: closest-hit keys, centre-visibility masks
     size_t cap_lit = 0, cap_best = 0;
     ContTask *d_tasks[2] = {nullptr, nullptr};   // continuation queues of k_shadow (tree scenes)
@@ -201,6 +204,8 @@ static void free_frame(rt_ctx *c) {
     if (c->d_items) (void)hipFree(c->d_items);
     if (c->d_vis) (void)hipFree(c->d_vis);
     if (c->d_sidx) (void)hipFree(c->d_sidx);
+    if (c->d_done) (void)hipFree(c->d_done);
+    c->d_done = nullptr; c->cap_done = 0;
     if (c->d_best) (void)hipFree(c->d_best);
     if (c->d_lit) (void)hipFree(c->d_lit);
     c->d_best = c->d_lit = nullptr; c->cap_lit = 0; c->cap_best = 0;
@@ -728,6 +733,15 @@ static rt_status ensure_frame(rt_ctx *c, size_t npix_frame, int levels, size_t s
         c->cap_pix = np; c->cap_levels = lv; c->cap_vis = vw; c->cap_lit = lw; c->cap_best = bs;
         ++c->frame_generation;
     }
+    // k_pair_beam's (item, light) bytes: only frames with several lights use them
+    if (lslots > 1 && c->cap_pix * lslots > c->cap_done) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_done) (void)hipFree(c->d_done);
+        c->d_done = nullptr; c->cap_done = 0;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&c->d_done), c->cap_pix * lslots + 64));
+        c->cap_done = c->cap_pix * lslots;
+        ++c->frame_generation;
+    }
     return RT_OK;
 }
 
@@ -820,11 +834,12 @@ static rt_status run_frame(rt_ctx *c, hipStream_t st, const DCam *cam, const DLi
         const bool beam = !count && c->S.beam != 0 && (c->flat || c->beam_trees);
         const uint32_t *sidx = (beam || item_beam) ? c->d_sidx : nullptr;
         if (beam) ++nl, launch_beam(c->cus * 4, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_sidx);
-        if (item_beam) ++nl, launch_pair_beam(c->cus * c->item_beam_blocks, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_sidx);
+        const uint8_t *pair_done = (item_beam && lslots > 1) ? c->d_done : nullptr;
+        if (item_beam) ++nl, launch_pair_beam(c->cus * c->item_beam_blocks, st, c->S, L, level, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis, c->d_sidx, lslots > 1 ? c->d_done : nullptr);
         const uint32_t shaft_b = level == 0 ? c->shaft_budget : c->shaft_budget_deep;
         if (shaft)
             ++nl, launch_shadow_shaft(c->cus * c->occ_shaft, st, c->S, L, level, 3 * level + 1, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis,
-                                c->d_tasks[0], c->task_cap, shaft_b, c->task_target, sidx);
+                                c->d_tasks[0], c->task_cap, shaft_b, c->task_target, sidx, pair_done);
         else
             ++nl, launch_shadow(count, c->flat, c->cus * c->occ_shadow, st, c->S, L, level, 3 * level + 1, lslots, F.item_cap, c->d_items, c->d_ctl, c->d_vis,
                           c->d_tasks[0], c->task_cap, c->shadow_budget, c->task_target, sidx);

@@ -93,6 +93,7 @@ struct TaskQueues {
     uint32_t cap, budget;         // queue capacity; leaves whose estimated cost (VALU instructions) exceeds `budget` are split into tasks (0 = off)
     uint32_t target = 0;          // estimated cost of one task piece (0: same as budget)
     uint32_t group_budget = 0;    // cone walk: groups a unit pops before it hands the rest of its stack to the task launch (0 = never)
+    const uint8_t *pair_done = nullptr;   // k_shadow_shaft behind k_pair_beam, several lights: byte (item, light) = 1 -- the beam has written that pair's words, skip its units
 };
 
 // blend kinds stored in rec[].w (bit pattern of a uint32)

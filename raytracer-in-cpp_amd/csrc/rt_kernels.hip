@@ -2778,6 +2778,12 @@ void k_shadow_shaft(const DNode *__restrict__ nodes, const TriRec *__restrict__ 
         const int l = static_cast<int>(g - item_i * static_cast<uint32_t>(lslots));
         uint32_t item_at = uniform_u32(sh * item_cap + item_i);
         if (sidx != nullptr) item_at = uniform_u32(sidx[item_at]);            // k_beam's survivors: position in the list -> item storage index
+        if (!CONT && Q.pair_done != nullptr) {
+            // several lights behind k_pair_beam: the beam of this (hit, light) pair found it unblocked and wrote its words (accounted for there)
+            const size_t di = static_cast<size_t>(item_at) * static_cast<size_t>(lslots) + static_cast<size_t>(l);
+            const uint32_t dw = reinterpret_cast<const uint32_t *>(Q.pair_done)[di >> 2];          // wave-uniform: a scalar load
+            if (((dw >> (8u * static_cast<uint32_t>(di & 3u))) & 0xffu) != 0u) continue;
+        }
         const ShadeItem it = items[item_at];                                  // wave-uniform: a scalar load
         uint32_t s = pass * 64u + static_cast<uint32_t>(lane);
         float fi = fi_lane + 0.5f, fj = fj_lane + 0.5f;                       // the lane's sample (i + 0.5, j + 0.5) -- P == 1: s = lane
@@ -3333,7 +3339,7 @@ __global__ __launch_bounds__(RT_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
 void k_pair_beam(const DNode *__restrict__ nodes, const TriRec *__restrict__ tris, const ChunkBound *__restrict__ chunks,
                  const DScene S, const DLights L, const int level, const int lslots, const uint32_t item_cap,
                  const ShadeItem *__restrict__ items, Control *__restrict__ ctl, unsigned long long *__restrict__ vis,
-                 uint32_t *__restrict__ sidx) {
+                 uint32_t *__restrict__ sidx, uint8_t *__restrict__ done) {
     __shared__ uint32_t s_node[RT_WAVES * RT_STACK];
     __shared__ float4 s_rec[RT_WAVES * RT_BEAM_REC];
     __shared__ float4 s_shaft[RT_WAVES * 16];
@@ -3390,7 +3396,13 @@ void k_pair_beam(const DNode *__restrict__ nodes, const TriRec *__restrict__ tri
         const ShadeItem it = items[idx];                                    // wave-uniform: a scalar load
         const float ax = it.ox + it.t * it.dx, ay = it.oy + it.t * it.dy, az = it.oz + it.t * it.dz;      // the hit, as the shadow kernels form it
         bool survive = it.lmode != 0u || give_up;          // (a mirror bounce carries a light list of its own: straight to the shadow units)
-        for (int l = 0; l < L.n_lights && !survive; ++l) {
+        // Several lights (`done`): a hit blocked from one light is still decided for the others -- every (hit, light) pair gets a byte, 1 = its
+        // words are written, and k_shadow_shaft skips the units of such pairs; the sample rays of a decided pair are accounted for here.
+        // One light: the first blocked light ends the hit's beams (it becomes a survivor, the unit kernel does all of it).
+        uint32_t n_decided = 0u;
+        if (done != nullptr && survive && lane < L.n_lights) done[static_cast<size_t>(idx) * static_cast<size_t>(lslots) + static_cast<uint32_t>(lane)] = 0;
+        const bool skip_all = survive;
+        for (int l = 0; l < L.n_lights && !skip_all && (done != nullptr || !survive); ++l) {
             float x0, y0, z0, x1, y1, z1;
             const float px = L.pos[l][0], py = L.pos[l][1], pz = L.pos[l][2];
             const LightGrid lg = light_grid(L, px, py, pz);
@@ -3438,8 +3450,10 @@ void k_pair_beam(const DNode *__restrict__ nodes, const TriRec *__restrict__ tri
                 blocked = __ballot(static_cast<uint32_t>(lane) < n_bad && !(dirs_ok && near_out && far_out)) != 0ull;
                 RT_PROF_ADD(lane, 78, 1); RT_PROF_ADD(lane, 79, blocked ? 1 : 0);
             }
+            if (done != nullptr && lane == 0) done[static_cast<size_t>(idx) * static_cast<size_t>(lslots) + static_cast<uint32_t>(l)] = blocked ? 0 : 1;
+            n_decided += blocked ? 0u : 1u;
             if (blocked) {
-                survive = true;              // (the words of lights already written stay: the unit kernel rewrites the same values)
+                survive = true;              // (one light: the words of lights already written stay, the unit kernel rewrites the same values)
             } else if (static_cast<uint32_t>(lane) < P) {
                 // nothing can block any sample segment of this hit to light l: all N samples visible (lane = pass)
                 const uint32_t left = N - static_cast<uint32_t>(lane) * 64u;
@@ -3452,6 +3466,7 @@ void k_pair_beam(const DNode *__restrict__ nodes, const TriRec *__restrict__ tri
             buf_shard = sh;
             if (lane == 0) buf[n_buf] = idx;
             if (++n_buf == RT_PAIR_BUF) flush();
+            if (done != nullptr) c_rays += N * n_decided;            // (the units of the decided pairs will be skipped)
         } else {
             c_rays += N * static_cast<uint32_t>(L.n_lights);        // sample rays that never become a shadow unit are accounted for here (wave-uniform)
         }
@@ -4172,8 +4187,10 @@ void launch_shadow(bool count, bool flat, int grid, hipStream_t st, const DScene
 }
 
 void launch_shadow_shaft(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int slot, int lslots, uint32_t item_cap,
-                         const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target, const uint32_t *sidx) {
-    const TaskQueues Q{nullptr, tasks_out, 0u, 2u, cap, budget, target};
+                         const ShadeItem *items, Control *ctl, unsigned long long *vis, ContTask *tasks_out, uint32_t cap, uint32_t budget, uint32_t target, const uint32_t *sidx,
+                         const uint8_t *pair_done) {
+    TaskQueues Q{nullptr, tasks_out, 0u, 2u, cap, budget, target};
+    Q.pair_done = pair_done;
     // (the task emission costs the walking kernel 30 more spilled registers: it is compiled in only when a budget asks for it)
     if (budget != 0u && tasks_out != nullptr)
         hipLaunchKernelGGL((k_shadow_shaft<false, true>), dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S, L, level, slot, lslots, item_cap, items, ctl, vis, Q, sidx);
@@ -4204,8 +4221,8 @@ void launch_beam(int grid, hipStream_t st, const DScene &S, const DLights &L, in
 }
 
 void launch_pair_beam(int grid, hipStream_t st, const DScene &S, const DLights &L, int level, int lslots, uint32_t item_cap, const ShadeItem *items, Control *ctl,
-                      unsigned long long *vis, uint32_t *sidx) {
-    hipLaunchKernelGGL(k_pair_beam, dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S, L, level, lslots, item_cap, items, ctl, vis, sidx);
+                      unsigned long long *vis, uint32_t *sidx, uint8_t *done) {
+    hipLaunchKernelGGL(k_pair_beam, dim3(grid), dim3(RT_WAVES * 64), 0, st, S.nodes, S.leaf_tris, S.chunks, S, L, level, lslots, item_cap, items, ctl, vis, sidx, done);
 }
 
 void launch_shade(int grid, hipStream_t st, const DScene &S, const DLights &L, const DFrame &F, int level, int slot, int lslots,

@@ -387,3 +387,23 @@ def test_lights_inside_close_to_and_far_from_the_model(rt, oracle, spot, us, mon
     ref, rhits, _ = osc.render(oracle.camera(w, h), oracle.lights(area=True, usteps=us, vsteps=us, points=[spot]), w, h, max_depth=depth, threads=8, want_hits=True)
     assert_exact(frames[0][0], frames[0][1], ref, rhits)
     osc.close(); hs.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("us,vs,n_lights", [(32, 32, 1), (12, 12, 25), (16, 24, 3)])
+def test_pair_beam_extremes_many_passes_many_lights(rt, oracle, us, vs, n_lights):
+    """16 passes per pair (32 x 32 samples: lane = pass writes 16 visibility words), the reference's maximum of 25 lights (25 light slots per
+    hit, three passes each), a non-square block grid (16 x 24: six passes, three blocks per row): dodge tree == oracle bit for bit."""
+    rng = np.random.default_rng(5)
+    pts = [(-1.0, 1.0, 1.0)] + [tuple(float(x) for x in rng.uniform(-1.2, 1.2, 3) + np.array([0.0, 0.0, 1.3])) for _ in range(n_lights - 1)]
+    path = os.path.join(SCENES, "dodgeColorTest.obj")
+    hs = rt.HostScene(path, 1000, 15)
+    ctx = rt.Context(0)
+    ctx.upload(hs)
+    osc = oracle.load_scene(path)
+    w, h, depth = 64, 40, 1
+    rgb, hits, st = _render_stats(rt, ctx, rt.default_camera(w, h), rt.make_lights(points=pts, area=True, usteps=us, vsteps=vs), w, h, depth)
+    ref, rhits, _ = osc.render(oracle.camera(w, h), oracle.lights(area=True, usteps=us, vsteps=vs, points=pts), w, h, max_depth=depth, threads=8, want_hits=True)
+    assert_exact(rgb, hits, ref, rhits)
+    assert 0 < st.rays_sample_walked < st.rays_sample
+    osc.close(); ctx.close(); hs.close()
