@@ -668,6 +668,15 @@ def main():
         print(json.dumps(out), flush=True)
         return
 
+    # RCCL prints a version banner on file descriptor 1 when its communicator comes up (NCCL_DEBUG=VERSION in this image): everything the
+    # libraries write to stdout goes to stderr from here on, and the ONE JSON line is written to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(real_stdout, (line + "\n").encode())
+
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
@@ -680,7 +689,7 @@ def main():
     if rank == 0:
         out = dict(base)
         out.update(rec)
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
         gf = rec.get("gathered_frame")
         bad = bool(gf) and not gf.get("match", True)
     dist.destroy_process_group()
