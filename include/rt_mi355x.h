@@ -151,6 +151,8 @@ rt_status rt_render(rt_ctx *ctx, const rt_camera *cam, const rt_lights *lights, 
  * stream: hipStream_t (NULL = the context's own stream).  Asynchronous when stats == NULL.                        */
 rt_status rt_render_device(rt_ctx *ctx, const rt_camera *cam, const rt_lights *lights, const rt_params *p,
                            float *d_out_rgb, uint8_t *d_out_u8, int32_t *d_out_hit, void *stream, rt_stats *stats);
+/* waits for the frames rt_render_device has enqueued (the context's stream and the stream of the latest call); reports a work-list overflow */
+rt_status rt_synchronize(rt_ctx *ctx);
 
 /* Sums the per-kernel device times (ms_* = SUM over frames, launches_* = total launches) of every frame rendered
  * with collect_stats == 2 since the last call, plus the ray counters of the last frame.  Synchronises the stream.  */

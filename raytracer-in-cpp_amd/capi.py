@@ -86,6 +86,7 @@ _SIGNATURES = [
     ("rt_stream", C.c_void_p, [C.c_void_p]),
     ("rt_upload_scene", C.c_int, [C.c_void_p, _P(rt_scene)]),
     ("rt_render", C.c_int, [C.c_void_p, _P(rt_camera), _P(rt_lights), _P(rt_params), C.c_void_p, C.c_void_p, _P(rt_stats)]),
+    ("rt_synchronize", C.c_int, [C.c_void_p]),
     ("rt_render_device", C.c_int, [C.c_void_p, _P(rt_camera), _P(rt_lights), _P(rt_params), C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, _P(rt_stats)]),
     ("rt_timing_collect", C.c_int, [C.c_void_p, _P(rt_stats)]),

@@ -1021,6 +1021,16 @@ static void make_cam(const rt_camera *cam, DCam *d) {
     d->k1 = scale;
 }
 
+// waits for every frame the context has enqueued (its own stream and the stream of the most recent rt_render_device call) and reports a
+// work-list overflow of any of them
+extern "C" rt_status rt_synchronize(rt_ctx *c) {
+    if (!c) return RT_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->last_frame_stream && c->last_frame_stream != c->stream) HIPCHK(c, hipStreamSynchronize(c->last_frame_stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return c->d_ctl ? check_overflow(c) : RT_OK;
+}
+
 extern "C" rt_status rt_render_device(rt_ctx *c, const rt_camera *cam, const rt_lights *lights, const rt_params *p,
                                       float *d_out_rgb, uint8_t *d_out_u8, int32_t *d_out_hit, void *stream, rt_stats *stats) {
     if (!c) return RT_ERR_INVALID;

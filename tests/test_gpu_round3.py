@@ -407,3 +407,24 @@ def test_pair_beam_extremes_many_passes_many_lights(rt, oracle, us, vs, n_lights
     assert_exact(rgb, hits, ref, rhits)
     assert 0 < st.rays_sample_walked < st.rays_sample
     osc.close(); ctx.close(); hs.close()
+
+
+@pytest.mark.gpu
+def test_synchronize_after_asynchronous_frames(rt, oracle):
+    """rt_render_device without a stats record is asynchronous; rt_synchronize waits for it.  Forty frames back to back on the context's stream,
+    one wait, the device buffer equals the oracle's frame."""
+    w, h, depth = 320, 200, 3
+    path = os.path.join(SCENES, "dodgeColorTest.obj")
+    hs = rt.HostScene(path, 1000, 15)
+    ctx = rt.Context(0)
+    ctx.upload(hs)
+    cam, L, p = rt.default_camera(w, h), rt.make_lights(area=True, usteps=8, vsteps=8), rt.make_params(w, h, depth)
+    out = rt.hipmem.DeviceBuffer(h * w * 3 * 4)
+    for _ in range(40):
+        rt.capi.check(ctx.lib, ctx.handle, ctx.lib.rt_render_device(ctx.handle, C.byref(cam), C.byref(L), C.byref(p), C.c_void_p(out.address), None, None, None, None), "render")
+    rt.capi.check(ctx.lib, ctx.handle, ctx.lib.rt_synchronize(ctx.handle), "rt_synchronize")
+    got = out.to_numpy(np.float32, (h, w, 3))
+    osc = oracle.load_scene(path)
+    ref, _, _ = osc.render(oracle.camera(w, h), oracle.lights(area=True, usteps=8, vsteps=8), w, h, max_depth=depth, threads=8)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    osc.close(); out.free(); ctx.close(); hs.close()

@@ -14,12 +14,10 @@ cam = pkg.default_camera(W, H); L = pkg.make_lights(area=True, usteps=G, vsteps=
 out = pkg.hipmem.DeviceBuffer(W * H * 3 * 4); out8 = pkg.hipmem.DeviceBuffer(W * H * 3)
 seen = {}
 t0 = time.time()
-st = pkg.capi.rt_stats()
 for i in range(n):
-    check = i % 50 == 0 or i == n - 1            # (rt_render_device is asynchronous unless it is given a stats record)
-    pkg.capi.check(ctx.lib, ctx.handle, ctx.lib.rt_render_device(ctx.handle, C.byref(cam), C.byref(L), C.byref(p), C.c_void_p(out.address), C.c_void_p(out8.address), None, None,
-                                                             C.byref(st) if check else None), "render")
-    if check:
+    pkg.capi.check(ctx.lib, ctx.handle, ctx.lib.rt_render_device(ctx.handle, C.byref(cam), C.byref(L), C.byref(p), C.c_void_p(out.address), C.c_void_p(out8.address), None, None, None), "render")
+    if i % 50 == 0 or i == n - 1:
+        pkg.capi.check(ctx.lib, ctx.handle, ctx.lib.rt_synchronize(ctx.handle), "rt_synchronize")         # (rt_render_device is asynchronous)
         h = hashlib.sha256(out8.to_numpy(np.uint8, (H, W, 3)).tobytes()).hexdigest()
         seen[h] = seen.get(h, 0) + 1
 print(scene, n, "frames in %.1f s;" % (time.time() - t0), "distinct frame hashes:", len(seen))
