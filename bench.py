@@ -315,6 +315,14 @@ def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, c
         shade["executed_valu"].update(clock_independent(ent["kernels"], lambda k: "k_shade" in k))
     else:
         shade["executed_valu"] = {"constant": True, "frac": None, "why": why or "no k_shade entry"}
+    tent, twhy = pmc_constant("traffic.json", scene, cfg, sha)
+    if tent and any("k_shade" in k for k in tent.get("kernels", {})):
+        tb = sum(v["hbm_bytes"] for k, v in tent["kernels"].items() if "k_shade" in k)
+        shade["traffic"] = int(tb)
+        shade["hbm_frac"] = round(tb / (max(ms_shade_frame, 1e-6) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        shade["traffic_source"] = "constant (level-0 launch of k_shade; divided by the frame's shade time over all levels): " + tent["how"]
+    else:
+        shade["traffic_source"] = twhy or "no k_shade entry in profiles/traffic.json"
     roof["ms_per_frame"] = {"trace": round(tim.ms_trace / K_t, 4), "shadow": round(ms_shadow_frame, 4), "shade": round(ms_shade_frame, 4), "device_total": round(tim.ms_total / K_t, 4),
                             "instrumented_frame": {"trace": round(brk.ms_trace, 4), "shadow": round(brk.ms_shadow, 4), "shade": round(brk.ms_shade, 4),
                                                    "resolve": round(brk.ms_resolve, 4), "total": round(brk.ms_total, 4)}}
@@ -342,6 +350,13 @@ def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, c
         trace["executed_valu"].update(clock_independent(ent["kernels"], sel))
     else:
         trace["executed_valu"] = {"constant": True, "frac": None, "why": why}
+    if tent and any(("k_trace" in k or "k_stage" in k) for k in tent.get("kernels", {})):
+        tb = sum(v["hbm_bytes"] for k, v in tent["kernels"].items() if "k_trace" in k or "k_stage" in k)
+        trace["traffic"] = int(tb)
+        trace["hbm_frac"] = round(tb / (max(ms_trace_frame, 1e-6) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        trace["traffic_source"] = "constant (heaviest launch of every trace kernel; divided by the frame's trace time over all levels): " + tent["how"]
+    else:
+        trace["traffic_source"] = twhy or "no trace kernels in profiles/traffic.json"
     # rays actually FORMED and walked: the frame's queries minus the sample segments whole tiles (k_beam) or whole (hit, light) units were proven
     # unblocked for before a ray existed.  `value` counts queries resolved; this is the traversal count behind it.
     rays_walked = int(cnt.rays_primary + cnt.rays_bounce + cnt.rays_centre + brk.rays_sample_walked)      # (brk: the instrumented frame of the shipped kernels)

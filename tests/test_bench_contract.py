@@ -96,6 +96,8 @@ def test_trace_group_walked_rays_launches_and_cpu_ratios(name, d):
     assert 0 < d["rays_walked_per_frame"] <= d["rays_per_frame"]
     assert abs(d["Mrays_walked_per_s"] - d["rays_walked_per_frame"] / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-3 * d["Mrays_walked_per_s"]
     if name == "cube headline":
+        # the counters of the group the headline roofline is about (k_shade) and of the trace group: HBM bytes per launch from the PMC passes
+        assert d["roofline"]["traffic"] > 0 and 0.0 < d["roofline"]["hbm_frac"] < 0.5 and d["roofline_trace"]["traffic"] > 0
         assert d["rays_walked_per_frame"] < 0.2 * d["rays_per_frame"]       # the beam test decides most sample segments without forming them
         assert d["launches_per_frame"] <= 12                                # memset + 4 + 4 + k_deep + resolve (22 before round 3)
     assert d["launches_per_frame"] >= 6

@@ -27,7 +27,19 @@ for sc in cfg:
         d = json.load(open(p))
         k = shadow_kernel(d, False)
         f, w = d[k]["FETCH_SIZE_KiB_max_launch"], d[k]["WRITE_SIZE_KiB_max_launch"]
+        # every kernel of the frame (heaviest launch): FETCH_SIZE x 2 + WRITE_SIZE; the counting-pass variants are left out
+        per_kernel = {}
+        for kk, vv in d.items():
+            args = [a.strip() for a in kk[kk.index("<") + 1:kk.rindex(">")].split(",")] if "<" in kk else []
+            count_arg = {"k_shadow": 0, "k_trace": 1, "k_stage": 1}.get(kk.split("::")[-1].split("<")[0])
+            if count_arg is not None and args and args[count_arg] == "true":
+                continue
+            if kk.split("::")[-1].startswith("k_shade<") and args[1] == "false" and any(q.split("::")[-1].startswith("k_shade<") and q.rstrip(">").endswith("true") for q in d):
+                continue
+            per_kernel[kk] = {"fetch_KiB": vv["FETCH_SIZE_KiB_max_launch"], "write_KiB": vv["WRITE_SIZE_KiB_max_launch"],
+                              "hbm_bytes": int((2 * vv["FETCH_SIZE_KiB_max_launch"] + vv["WRITE_SIZE_KiB_max_launch"]) * 1024)}
         traffic[sc] = {
+            "kernels": per_kernel,
             "kernel": k, "fetch_KiB_per_launch": f, "write_KiB_per_launch": w, "hbm_bytes_per_launch": int((2 * f + w) * 1024),
             "how": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --scene {sc} --steps 2 --warmup 1` "
                    "(tools/traffic.sh); level-0 launch; FETCH_SIZE doubled per the gfx950 rule of MI355X_MICROARCH.md §HBM (calibrated there "
