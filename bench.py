@@ -191,7 +191,7 @@ def pmc_constant(fname, scene, cfg, sha):
 
 
 def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, cpu_stride, want_graph, want_work=True):
-    """N = 1: eager launches with per-kernel HIP events on every 4th step; returns the record of this workload"""
+    """N = 1: eager launches with per-kernel HIP events on about four of the timed steps; returns the record of this workload"""
     import numpy as np
     capi = pkg.capi
     scene_file, scene_path = scene_of(scene)
@@ -228,8 +228,11 @@ def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, c
     # ---- timed region: EXACTLY K steps between synchronisations
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
+    # per-kernel HIP events on about four of the timed steps (their ~17 event records cost ~40-60 us of a 0.3 ms frame: every 4th step, as until
+    # round 3, put ~3 % on the headline)
+    period = 4 if steps < 16 else steps // 4
     for i in range(steps):
-        render(p_timed if i % 4 == 0 else p_plain)      # per-kernel HIP events on every 4th step (the ~17 event records cost ~60 us)
+        render(p_timed if i % period == 0 else p_plain)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     tim = capi.rt_stats()
@@ -237,7 +240,7 @@ def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, c
     brk = capi.rt_stats()
     render(_p(0), brk)                                   # untimed: an event between every pair of launches
     torch.cuda.synchronize(dev)
-    K_t = (steps + 3) // 4
+    K_t = (steps + period - 1) // period
     ms_step = elapsed / steps * 1e3
     value = rays_frame * steps / elapsed / 1e6
     launches = max(1, tim.launches_shadow)
@@ -292,7 +295,7 @@ def run_single(pkg, torch, dev, scene, W, H, G, D, S, steps, warmup, want_cpu, c
     roof["avg_launch_ms"] = round(avg_ms_shadow, 5)
     roof["launches_per_frame"] = launches_per_frame
     roof["group"] = "shadow"
-    roof["timing_source"] = f"HIP events on the launch stream inside the timed region (every 4th step: {K_t} of {steps} frames)"
+    roof["timing_source"] = f"HIP events on the launch stream inside the timed region (every {period}th step: {K_t} of {steps} frames)"
     # ---- the shading kernel, same model: tiles of 64 hits x samples
     ms_shade_frame = tim.ms_shade / K_t
     tiles = (cnt.shaded_hits + 63) // 64
